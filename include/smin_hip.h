@@ -1,0 +1,123 @@
+/* smin_hip.h -- C ABI of the MI355X (gfx950) SMIN hot path: cross-modal fusion + 2D temporal
+ * proposal scoring of ChanukyaVardhan/Video-Moment-Localization (reference models.py).
+ *
+ * The reference has no FFI of its own (pure PyTorch): its de-facto operator boundary is
+ * the nn.Module surface of models.py.  Each entry point below replaces the body of one of those
+ * modules' forward() (cited per function) for fwd and for the autograd backward torch would derive.
+ * The Python host (video-moment-localization_amd/) binds these with ctypes and keeps the reference's
+ * module/ctor/forward/state_dict surface.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; `stream` is a hipStream_t.
+ *   - all calls are asynchronous on `stream`, allocate nothing and never synchronise (graph-capturable);
+ *     scratch comes from the caller-provided workspace `ws` (size from smin_workspace_bytes).
+ *   - return 0 on success, a positive hipError_t, or a negative code for a rejected argument.
+ *   - requirements: D % 4 == 0, dl % 4 == 0, dl <= 128, 2 <= C <= 4, Nq <= 32.
+ *
+ * Packed valid-cell layout: the L x L map is stored as a list of N cells sorted by
+ * (b, i, j):  cells[n] = {b, i, j, m} (int32 x4, m = moment_mask[b,i,j]);
+ *             row_ptr[b*L+i] .. row_ptr[b*L+i+1] = the cells of start-snippet row (b, i)  (B*L+1 ints);
+ *             cellmap[b][i][j] = n or -1.
+ * Per-cell tensors: f_c [N][C][D], f_m [N][D].  With moment-mask driven lists (m == 1 everywhere) this
+ * is bit-equivalent to the reference's dense (B,L,L,..) tensors, whose masked cells are exactly zero;
+ * with a list of all B*L*L cells it reproduces the dense sub-module seams for arbitrary inputs.
+ */
+#ifndef SMIN_HIP_H
+#define SMIN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMIN_HIP_ABI_VERSION 1
+
+int smin_abi_version(void);
+/* "gfx950" -- the only code object in the library */
+const char* smin_target_arch(void);
+/* bytes of scratch any single call below may need for N cells (C, D, dl, Nq, B as given) */
+size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int Nq);
+
+/* ---- ProposalGeneration.forward (models.py:115-126) with compute_content_matrix (models.py:88-98)
+ * as index arithmetic: fc[n,c,:] = mean of f[b, start..start+cs) per clip, fm = mean_c fc (divides by C),
+ * fb = AvgPool1d(T/L) over time.  f [B][T][D]; fc [N][C][D]; fm [N][D]; fb [B][L][D]. */
+int smin_proposal_map_fwd(void* stream, const float* f, const int32_t* cells, int N, int B, int T, int L, int C, int D,
+                          float* fc, float* fm, float* fb, void* ws, size_t ws_bytes /* >= 8*B*(T+1)*D */);
+/* df [B][T][D] = d/df of the three outputs (any of dfc/dfm/dfb may be NULL = zero).  ws_bytes >= 4*B*T*D. */
+int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, const float* dfb,
+                          const int32_t* cells, const int32_t* cellmap, int N, int B, int T, int L, int C, int D,
+                          float* df, void* ws, size_t ws_bytes);
+
+/* ---- ContentUnit.forward (models.py:242-276) incl. ContentAttention.forward (models.py:207-226).
+ * Query-side per-sample operands are prepared by the host (O(B*Nq*dl) work):
+ *   what [B][Nq][dl] = linear_w_hat(f_w) * query_mask          shat [B][dl] = linear_s_hat(f_s)
+ *   Mq   [B][Nq][dl] = W_k(what) @ W_q.weight                   uq   [B][Nq] = W_k(what) @ W_q.bias
+ *   (so that  W_q(c_hat) . W_k(what)^T  ==  c_hat . Mq^T + uq  -- the per-cell dl x dl projection folds away)
+ *   qmask [B][Nq] fp32 0/1.
+ * Outputs: fc_out [N][C][D], fcmean [N][D] = mean_c fc_out (consumed by the moment unit);
+ * saved for backward: chat [N*C][dl], cchat [N*C][dl]. */
+int smin_content_unit_fwd(void* stream, const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
+                          int N, int B, int L, int C, int D, int dl, int Nq,
+                          const float* fs, const float* Wch, const float* bch, const float* Mq, const float* uq,
+                          const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
+                          float* fc_out, float* fcmean, float* chat, float* cchat);
+/* Backward.  dfc_out may be NULL (last layer: only the moment unit consumes fc_out, through fcmean).
+ * WcT [dl][D] and WchT [D][dl] are transposed copies of the weights.
+ * Gradients: dfc [N][C][D], dfm [N][D] (gate path only), dfs [B][D] (gate path only), dWch [dl][D], dbch [dl],
+ * dMq [B][Nq][dl], duq [B][Nq], dwhat [B][Nq][dl], dshat [B][dl], dWc [D][dl], dbc [D]. */
+int smin_content_unit_bwd(void* stream, const float* dfc_out, const float* dfcmean,
+                          const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
+                          int N, int B, int L, int C, int D, int dl, int Nq,
+                          const float* fs, const float* Wch, const float* WchT, const float* Mq, const float* uq,
+                          const float* what, const float* shat, const float* qmask, const float* WcT,
+                          const float* chat, const float* cchat,
+                          float* dfc, float* dfm, float* dfs, float* dWch, float* dbch, float* dMq, float* duq,
+                          float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes);
+
+/* ---- BoundaryUnit.forward, the map-sized part (models.py:190-194):
+ *   fbm[b,i,:] = sum_j A_b[b,i,j] * sigmoid(f_m[(b,i,j)] * f_s[b]) * f_m[(b,i,j)]
+ * A_b [B][L][L] comes from the L x L boundary self-attention (models.py:164-188), which the host runs
+ * as plain library GEMMs.  fbm [B][L][D]. */
+int smin_boundary_reduce_fwd(void* stream, const float* Ab, const float* fm, const float* fs, const int32_t* cells,
+                             const int32_t* row_ptr, int N, int B, int L, int D, float* fbm);
+/* dAb [B][L][L] (zero where no cell), dfm [N][D], dfs [B][D]. */
+int smin_boundary_reduce_bwd(void* stream, const float* dfbm, const float* Ab, const float* fm, const float* fs,
+                             const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int D,
+                             float* dAb, float* dfm, float* dfs, void* ws, size_t ws_bytes);
+
+/* ---- MomentUnit.forward (models.py:288-303): two 1x1 convs fused into one K = 2D contraction
+ *   mu[n,:] = m * ( [fb[b,i]*fb[b,j] | fcmean[n]] @ Wcat^T + bcat ) + fm[n,:]
+ * Wcat [D][2D] = [conv_layer_fb.weight | conv_layer_fc.weight], bcat [D] = sum of the two biases. */
+int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
+                         int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu);
+/* WcatT [2D][D].  dfcmean [N][D], dfb [B][L][D], dWcat [D][2D], dbcat [D]; the residual gradient
+ * d mu / d fm is the identity and is left to the caller (dfm += dmu). */
+int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
+                         const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
+                         float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes);
+
+/* ---- Localization.forward (models.py:335-344): score heads.
+ *   pm [B][L][L] dense, zero-filled outside the cell list;  wb [3][D], bb [3] = (ps, pe, pa) heads;
+ *   psea [3][B][L];  lmask [B][L] fp32 0/1. */
+int smin_score_map_fwd(void* stream, const float* fm, const float* fb, const int32_t* cells, int N, int B, int L, int D,
+                       const float* wm, const float* bm, const float* wb, const float* bb, const float* lmask,
+                       float* pm, float* psea);
+/* dpm [B][L][L], dpsea [3][B][L] -> dfm [N][D], dfb [B][L][D], dwm [D], dbm [1], dwb [3][D], dbb [3]. */
+int smin_score_map_bwd(void* stream, const float* dpm, const float* dpsea, const float* pm, const float* psea,
+                       const float* fm, const float* fb, const int32_t* cells, int N, int B, int L, int D,
+                       const float* wm, const float* wb, const float* lmask,
+                       float* dfm, float* dfb, float* dwm, float* dbm, float* dwb, float* dbb, void* ws, size_t ws_bytes);
+
+/* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
+int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
+int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);
+
+/* ---- stand-alone fp32 MFMA GEMM  C[M][N] = A[M][K] * B[N][K]^T  (used by tests and bench.py's
+ * roofline probe; same engine as every contraction above). */
+int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMIN_HIP_H */

@@ -1,0 +1,17 @@
+"""MI355X-native SMIN hot path (cross-modal fusion + 2D temporal proposal scoring).
+
+Drop-in for the ``models.py`` module surface of ChanukyaVardhan/Video-Moment-Localization:
+same classes, constructor/forward signatures and state_dict keys, with the
+per-cell work done by hand-written HIP kernels for gfx950 behind the C ABI in
+``include/smin_hip.h`` (``libsmin_hip.so``, bound with ctypes in ``_lib.py``).
+
+The directory name contains '-' so it cannot be imported by name; the repo-root ``models.py``
+loads it under the module name ``vml_amd``.
+"""
+from . import _lib  # noqa: F401
+from .cells import CellLayout  # noqa: F401
+from .modules import (  # noqa: F401
+    SMIN, SMI, Attention, Backbone, BoundaryUnit, ContentAttention, ContentUnit, Localization,
+    MomentUnit, ProposalGeneration, QueryEncoder, VideoEncoder, compute_content_matrix,
+)
+from .training import loss_fn, bce_loss, compute_ious  # noqa: F401

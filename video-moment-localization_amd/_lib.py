@@ -1,0 +1,107 @@
+"""ctypes binding of libsmin_hip.so (C ABI: include/smin_hip.h).  No CPU fallback: every entry point
+raises if the library is missing or a tensor is not on a HIP device."""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmin_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/smin_hip.h one to one
+SIGNATURES = {
+    "smin_abi_version": [],
+    "smin_target_arch": [],
+    "smin_workspace_bytes": [_i] * 6,
+    "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
+    "smin_proposal_map_bwd": [_vp] * 6 + [_i] * 6 + [_vp, _vp, _sz],
+    "smin_content_unit_fwd": [_vp] * 5 + [_i] * 7 + [_vp] * 10 + [_vp] * 4,
+    "smin_content_unit_bwd": [_vp] * 7 + [_i] * 7 + [_vp] * 11 + [_vp] * 11 + [_vp, _sz],
+    "smin_boundary_reduce_fwd": [_vp] * 6 + [_i] * 4 + [_vp],
+    "smin_boundary_reduce_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 3 + [_vp, _sz],
+    "smin_moment_unit_fwd": [_vp] * 5 + [_i] * 4 + [_vp] * 3,
+    "smin_moment_unit_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz],
+    "smin_score_map_fwd": [_vp] * 4 + [_i] * 4 + [_vp] * 7,
+    "smin_score_map_bwd": [_vp] * 8 + [_i] * 4 + [_vp] * 3 + [_vp] * 6 + [_vp, _sz],
+    "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
+}
+_RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz}
+
+_lib = None
+_ws = {}
+
+
+class SminHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libsmin_hip.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise SminHipError("building libsmin_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SminHipError(
+            f"{LIB_PATH} is missing: the SMIN hot path has no CPU fallback. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, _i)
+    if lib.smin_abi_version() != 1:
+        raise SminHipError("libsmin_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SminHipError("the SMIN hot path runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise SminHipError("internal error: non-contiguous tensor handed to the C ABI")
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float64):
+        raise SminHipError(f"unsupported dtype {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Persistent per-device scratch buffer, grown on demand (calls are stream-ordered)."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def check(rc, name):
+    if rc != 0:
+        raise SminHipError(f"{name} failed with code {rc}" + (" (argument rejected at csrc line %d)" % (-rc - 1000) if rc < -1000 else ""))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,49 @@
+"""Packed valid-cell layout of the L x L proposal map.
+
+The reference keeps dense (B, L, L, ...) tensors whose masked cells are exactly zero after every
+layer; the kernels instead work on the sorted list of cells that are present.  Two lists are used:
+``from_mask`` (cells with moment_mask == 1; the in-model fast path) and ``all_cells`` (every
+(b, i, j) with its mask flag; reproduces the dense sub-module seams for arbitrary inputs)."""
+import torch
+
+
+class CellLayout:
+    __slots__ = ("cells", "row_ptr", "cellmap", "N", "B", "L", "bidx", "iidx", "jidx")
+
+    def __init__(self, cells, row_ptr, cellmap, B, L, idx):
+        self.cells, self.row_ptr, self.cellmap = cells, row_ptr, cellmap
+        self.N, self.B, self.L = int(cells.shape[0]), B, L
+        self.bidx, self.iidx, self.jidx = idx[:, 0], idx[:, 1], idx[:, 2]
+
+    @staticmethod
+    def _build(present, flag):
+        B, L, _ = present.shape
+        idx = present.nonzero()                                   # (N, 3) sorted by (b, i, j); one host sync
+        N = idx.shape[0]
+        m = flag[idx[:, 0], idx[:, 1], idx[:, 2]].to(torch.int32).unsqueeze(1)
+        cells = torch.cat([idx.to(torch.int32), m], dim=1).contiguous()
+        counts = present.sum(dim=2).reshape(-1)
+        row_ptr = torch.zeros(B * L + 1, dtype=torch.int32, device=present.device)
+        row_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        cellmap = torch.full((B, L, L), -1, dtype=torch.int32, device=present.device)
+        cellmap[idx[:, 0], idx[:, 1], idx[:, 2]] = torch.arange(N, dtype=torch.int32, device=present.device)
+        return CellLayout(cells, row_ptr, cellmap, B, L, idx)
+
+    @staticmethod
+    def from_mask(moment_mask):
+        mm = moment_mask != 0
+        return CellLayout._build(mm, mm)
+
+    @staticmethod
+    def all_cells(moment_mask):
+        mm = moment_mask != 0
+        return CellLayout._build(torch.ones_like(mm), mm)
+
+    # dense (B, L, L, ...) <-> packed (N, ...) through torch indexing (differentiable; seams only)
+    def pack(self, dense):
+        return dense[self.bidx, self.iidx, self.jidx].contiguous()
+
+    def unpack(self, packed):
+        out = packed.new_zeros((self.B, self.L, self.L) + tuple(packed.shape[1:]))
+        out[self.bidx, self.iidx, self.jidx] = packed
+        return out

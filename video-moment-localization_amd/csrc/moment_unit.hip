@@ -1,0 +1,100 @@
+// MomentUnit (reference models.py:278-303): the two 1x1 Conv2d(D, D) are per-cell linear maps; they are fused into
+// one K = 2D contraction whose left operand [f_b[i]*f_b[j] | mean_c f_c] is generated on the fly (never stored):
+//   mu[n,:] = m[n] * ( X[n,:] @ Wcat^T + bcat ) + fm[n,:]
+// This is ~46% of the path's FLOPs (4*D^2 per cell) and runs on the fp32 MFMA GEMM engine.
+#include "gemm.h"
+#include "smin_hip.h"
+
+namespace smin {
+
+struct EpMomentOut {                // mu = (acc + bcat) * m + fm
+    const float* bcat; const int* cells; const float* fm; float* out; int M, N;
+    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
+        if (col >= N) return;
+        const float b = bcat[col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = row0 + q;
+            if (row < M) out[(size_t)row * N + col] = (v[q] + b) * (float)cells[4 * (size_t)row + 3] + fm[(size_t)row * N + col];
+        }
+    }
+};
+
+struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean
+    float* dx1; float* dmean; int M, D;
+    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
+        if (col >= 2 * D) return;
+        float* dst = col < D ? dx1 + col : dmean + (col - D);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (row0 + q < M) dst[(size_t)(row0 + q) * D] = v[q];
+    }
+};
+
+// dfb[b][l][:] = sum_{cells (l, j)} dX1[n] * fb[b][j]  +  sum_{cells (i, l)} dX1[n] * fb[b][i]
+// (gradient of the outer product f_b[i]*f_b[j]; the diagonal cell (l, l) contributes through both sums).
+// One 128-thread workgroup per (b, l); gather only -> deterministic.
+__global__ __launch_bounds__(128)
+void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ fb, const int* __restrict__ cells,
+                       const int* __restrict__ row_ptr, const int* __restrict__ cellmap, int L, int D, float* __restrict__ dfb)
+{
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* fbb = fb + (size_t)b * L * D;
+    const int r0 = row_ptr[b * L + l], r1 = row_ptr[b * L + l + 1];
+    const int* cmap = cellmap + (size_t)b * L * L;
+    for (int d = threadIdx.x * 4; d < D; d += 512) {
+        float4 acc = f4zero();
+        for (int n = r0; n < r1; ++n) {                                   // row l: partner is the end snippet j
+            const int j = cells[4 * (size_t)n + 2];
+            acc = f4add(acc, f4mul(ldg4(dx1 + (size_t)n * D + d), ldg4(fbb + (size_t)j * D + d)));
+        }
+        for (int i = 0; i < L; ++i) {                                     // column l: partner is the start snippet i
+            const int n = cmap[i * L + l];
+            if (n >= 0) acc = f4add(acc, f4mul(ldg4(dx1 + (size_t)n * D + d), ldg4(fbb + (size_t)i * D + d)));
+        }
+        stg4(dfb + ((size_t)b * L + l) * D + d, acc);
+    }
+}
+
+}  // namespace smin
+
+using namespace smin;
+
+extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
+                                    int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu)
+{
+    (void)B;
+    SMIN_REQUIRE(D % 4 == 0);
+    return launch_gemm_nt((hipStream_t)stream, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D},
+                          EpMomentOut{bcat, cells, fm, mu, N, D}, N, D, 2 * D);
+}
+
+extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
+                                    const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
+                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
+    float* w = reinterpret_cast<float*>(ws);
+    const int sp = N > 0 ? tn_splits(N, D, 2 * D) : 1;
+    float* dx1 = w;
+    float* slab = dx1 + (((size_t)N * D + 3) & ~(size_t)3);
+    float* bslab = slab + (size_t)sp * D * 2 * D;
+    SMIN_REQUIRE((size_t)((bslab + (size_t)sp * D) - w) * sizeof(float) <= ws_bytes);
+    if (N > 0) {
+        // dX = (m * dmu) @ Wcat        [N, 2D], contraction over D
+        int rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, N, D}, N, 2 * D, D);
+        if (rc) return rc;
+        // dWcat[D, 2D] = (m * dmu)^T @ X ; dbcat = colsum(m * dmu)
+        rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+        if (rc) return rc;
+        rc = launch_reduce_slabs(st, slab, dWcat, D * 2 * D, sp); if (rc) return rc;
+        rc = launch_reduce_slabs(st, bslab, dbcat, D, sp); if (rc) return rc;
+    } else {
+        hipMemsetAsync(dWcat, 0, sizeof(float) * (size_t)D * 2 * D, st);
+        hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
+    }
+    hipLaunchKernelGGL(moment_dfb_kernel, dim3(L, B), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, L, D, dfb);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}

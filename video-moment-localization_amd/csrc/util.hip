@@ -1,0 +1,100 @@
+// Library identity, workspace sizing, slab reduction, dense<->packed layout helpers, stand-alone GEMM.
+#include "gemm.h"
+#include "smin_hip.h"
+
+namespace smin {
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int P)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < P; ++z) s += slab[(size_t)z * n + idx];
+    out[idx] = s;
+}
+
+int launch_reduce_slabs(hipStream_t st, const float* slab, float* out, int n, int P)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, out, n, P);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void pack_cells_kernel(const float* __restrict__ dense, const int* __restrict__ cells, int N, int L, int W4, float* __restrict__ packed)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * W4) return;
+    const size_t n = idx / W4; const int k = (int)(idx % W4);
+    const Cell c = load_cell(cells, (int)n);
+    const size_t src = (((size_t)c.b * L + c.i) * L + c.j) * W4 + k;
+    stg4(packed + idx * 4, ldg4(dense + src * 4));
+}
+
+__global__ void unpack_cells_kernel(const float* __restrict__ packed, const int* __restrict__ cells, int N, int L, int W4, float* __restrict__ dense)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * W4) return;
+    const size_t n = idx / W4; const int k = (int)(idx % W4);
+    const Cell c = load_cell(cells, (int)n);
+    const size_t dst = (((size_t)c.b * L + c.i) * L + c.j) * W4 + k;
+    stg4(dense + dst * 4, ldg4(packed + idx * 4));
+}
+
+struct EpStore {
+    float* out; int M, N;
+    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
+        if (col >= N) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (row0 + q < M) out[(size_t)(row0 + q) * N + col] = v[q];
+    }
+};
+
+}  // namespace smin
+
+using namespace smin;
+
+extern "C" int smin_abi_version(void) { return SMIN_HIP_ABI_VERSION; }
+extern "C" const char* smin_target_arch(void) { return "gfx950"; }
+
+extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int Nq)
+{
+    (void)Nq;
+    const size_t M = (size_t)N * C;
+    // content unit bwd: 2 x [M][dl] + TN slabs (<= 64 splits) + attention slabs + gate partials
+    size_t content = 2 * M * dl + 2 * (size_t)64 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * 4 * ((size_t)2 * 32 * dl + dl + 32) + (size_t)B * 64 * D;
+    // moment unit bwd: dX1 [N][D] + slabs [64][D][2D] + bias slabs
+    size_t moment = (size_t)N * D + (size_t)64 * ((size_t)D * 2 * D + D);
+    // boundary / score: per-row partials
+    size_t other = (size_t)N + 8 * (size_t)B * 64 * D + (size_t)N * 4;
+    size_t fl = content > moment ? content : moment;
+    if (other > fl) fl = other;
+    return (fl + 1024) * sizeof(float);
+}
+
+extern "C" int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed)
+{
+    SMIN_REQUIRE(W % 4 == 0);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (W / 4);
+    hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dense, cells, N, L, W / 4, packed);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense)
+{
+    SMIN_REQUIRE(W % 4 == 0);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (W / 4);
+    hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed, cells, N, L, W / 4, dense);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K)
+{
+    SMIN_REQUIRE(K % 4 == 0);
+    return launch_gemm_nt((hipStream_t)stream, PlainMat{A, K}, PlainMat{Bm, K}, EpStore{Cm, M, N}, M, N, K);
+}

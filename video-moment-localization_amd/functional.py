@@ -1,0 +1,204 @@
+"""autograd.Function wrappers around the C ABI (include/smin_hip.h).
+
+Each Function owns one reference module body (fwd) and the backward torch autograd would have derived
+for it; they compose under ordinary autograd, so DistributedDataParallel hooks fire as usual.
+All tensors are fp32, contiguous, on one HIP device; kernels launch on torch's current stream."""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _ws(nbytes, device):
+    buf = _lib.workspace(nbytes, device)
+    return buf, ptr(buf), buf.numel()
+
+
+def _unit_ws(layout, C, D, dl, Nq, device):
+    n = _lib.load().smin_workspace_bytes(layout.N, layout.B, C, D, dl, Nq)
+    return _ws(n, device)
+
+
+class ProposalMapFn(Function):
+    """ProposalGeneration.forward (reference models.py:115-126)."""
+
+    @staticmethod
+    def forward(ctx, f, layout, T, L, C):
+        f = _c(f)
+        B, Tn, D = f.shape
+        if Tn != T:
+            raise ValueError(f"ProposalGeneration was built for T={T} but got {Tn} frames")
+        fc = f.new_empty((layout.N, C, D))
+        fm = f.new_empty((layout.N, D))
+        fb = f.new_empty((B, L, D))
+        _, wp, wn = _ws(8 * B * (T + 1) * D, f.device)
+        call("smin_proposal_map_fwd", stream(), ptr(f), ptr(layout.cells), layout.N, B, T, L, C, D, ptr(fc), ptr(fm), ptr(fb), wp, wn)
+        ctx.layout, ctx.dims = layout, (B, T, L, C, D)
+        return fc, fm, fb
+
+    @staticmethod
+    def backward(ctx, dfc, dfm, dfb):
+        layout = ctx.layout
+        B, T, L, C, D = ctx.dims
+        dfc, dfm, dfb = _c(dfc), _c(dfm), _c(dfb)
+        ref = dfc if dfc is not None else dfm if dfm is not None else dfb
+        df = ref.new_empty((B, T, D))
+        _, wp, wn = _ws(4 * B * T * D, df.device)
+        call("smin_proposal_map_bwd", stream(), ptr(dfc), ptr(dfm), ptr(dfb), ptr(layout.cells), ptr(layout.cellmap),
+             layout.N, B, T, L, C, D, ptr(df), wp, wn)
+        return df, None, None, None, None
+
+
+class ContentUnitFn(Function):
+    """ContentUnit.forward + ContentAttention.forward (reference models.py:207-226, 242-276).
+
+    Inputs: fc [N,C,D], fm [N,D], fs [B,D], linear_c_hat (Wch, bch), the folded word-side operands
+    Mq/uq/what/shat (see smin_hip.h), qmask [B,Nq] fp32, linear_c (Wc, bc).
+    Outputs: fc_out [N,C,D], fcmean [N,D]."""
+
+    @staticmethod
+    def forward(ctx, fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc, layout):
+        fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc = map(_c, (fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc))
+        N, C, D = fc.shape
+        B, Nq, dl = what.shape
+        fc_out = torch.empty_like(fc)
+        fcmean = fc.new_empty((N, D))
+        chat = fc.new_empty((N * C, dl))
+        cchat = fc.new_empty((N * C, dl))
+        call("smin_content_unit_fwd", stream(), ptr(fc), ptr(fm), ptr(layout.cells), ptr(layout.row_ptr), N, B, layout.L, C, D, dl, Nq,
+             ptr(fs), ptr(Wch), ptr(bch), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(Wc), ptr(bc),
+             ptr(fc_out), ptr(fcmean), ptr(chat), ptr(cchat))
+        ctx.save_for_backward(fc, fm, fs, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat)
+        ctx.layout = layout
+        return fc_out, fcmean
+
+    @staticmethod
+    def backward(ctx, dfc_out, dfcmean):
+        fc, fm, fs, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat = ctx.saved_tensors
+        layout = ctx.layout
+        N, C, D = fc.shape
+        B, Nq, dl = what.shape
+        dfc_out = _c(dfc_out)
+        dfcmean = _c(dfcmean) if dfcmean is not None else fm.new_zeros((N, D))
+        WchT, WcT = Wch.t().contiguous(), Wc.t().contiguous()
+        dfc, dfm, dfs = torch.empty_like(fc), torch.empty_like(fm), torch.empty_like(fs)
+        dWch, dbch = torch.empty_like(Wch), fc.new_empty((dl,))
+        dMq, duq, dwhat, dshat = torch.empty_like(Mq), torch.empty_like(uq), torch.empty_like(what), torch.empty_like(shat)
+        dWc, dbc = torch.empty_like(Wc), fc.new_empty((D,))
+        if N == 0:
+            for t in (dfs, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc):
+                t.zero_()
+        else:
+            _, wp, wn = _unit_ws(layout, C, D, dl, Nq, fc.device)
+            call("smin_content_unit_bwd", stream(), ptr(dfc_out), ptr(dfcmean), ptr(fc), ptr(fm), ptr(layout.cells), ptr(layout.row_ptr),
+                 N, B, layout.L, C, D, dl, Nq, ptr(fs), ptr(Wch), ptr(WchT), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(WcT),
+                 ptr(chat), ptr(cchat), ptr(dfc), ptr(dfm), ptr(dfs), ptr(dWch), ptr(dbch), ptr(dMq), ptr(duq), ptr(dwhat), ptr(dshat),
+                 ptr(dWc), ptr(dbc), wp, wn)
+        return dfc, dfm, dfs, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None
+
+
+class BoundaryReduceFn(Function):
+    """The map-sized term of BoundaryUnit.forward (reference models.py:190-194)."""
+
+    @staticmethod
+    def forward(ctx, Ab, fm, fs, layout):
+        Ab, fm, fs = _c(Ab), _c(fm), _c(fs)
+        B, L, _ = Ab.shape
+        D = fm.shape[1]
+        fbm = fm.new_empty((B, L, D))
+        call("smin_boundary_reduce_fwd", stream(), ptr(Ab), ptr(fm), ptr(fs), ptr(layout.cells), ptr(layout.row_ptr),
+             layout.N, B, L, D, ptr(fbm))
+        ctx.save_for_backward(Ab, fm, fs)
+        ctx.layout = layout
+        return fbm
+
+    @staticmethod
+    def backward(ctx, dfbm):
+        Ab, fm, fs = ctx.saved_tensors
+        layout = ctx.layout
+        B, L, _ = Ab.shape
+        D = fm.shape[1]
+        dfbm = _c(dfbm)
+        dAb, dfm, dfs = torch.empty_like(Ab), torch.empty_like(fm), torch.empty_like(fs)
+        _, wp, wn = _ws(4 * B * L * D, fm.device)
+        call("smin_boundary_reduce_bwd", stream(), ptr(dfbm), ptr(Ab), ptr(fm), ptr(fs), ptr(layout.cells), ptr(layout.row_ptr),
+             layout.N, B, L, D, ptr(dAb), ptr(dfm), ptr(dfs), wp, wn)
+        return dAb, dfm, dfs, None
+
+
+class MomentUnitFn(Function):
+    """MomentUnit.forward (reference models.py:288-303); Wcat = [conv_fb.W | conv_fc.W] (D, 2D)."""
+
+    @staticmethod
+    def forward(ctx, fcmean, fm, fb, Wcat, bcat, layout):
+        fcmean, fm, fb, Wcat, bcat = map(_c, (fcmean, fm, fb, Wcat, bcat))
+        N, D = fm.shape
+        B, L, _ = fb.shape
+        mu = torch.empty_like(fm)
+        call("smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu))
+        ctx.save_for_backward(fcmean, fb, Wcat)
+        ctx.layout = layout
+        return mu
+
+    @staticmethod
+    def backward(ctx, dmu):
+        fcmean, fb, Wcat = ctx.saved_tensors
+        layout = ctx.layout
+        N, D = fcmean.shape
+        B, L, _ = fb.shape
+        dmu = _c(dmu)
+        WcatT = Wcat.t().contiguous()
+        dfcmean, dfb = torch.empty_like(fcmean), torch.empty_like(fb)
+        dWcat, dbcat = torch.empty_like(Wcat), fb.new_empty((D,))
+        _, wp, wn = _unit_ws(layout, 4, D, 4, 1, fb.device)
+        call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcmean), ptr(fb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
+             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn)
+        return dfcmean, dmu, dfb, dWcat, dbcat, None
+
+
+class ScoreMapFn(Function):
+    """Localization.forward (reference models.py:335-344).  Returns pm (B,L,L) dense and psea (3,B,L)."""
+
+    @staticmethod
+    def forward(ctx, fm, fb, wm, bm, wb, bb, lmask, layout):
+        fm, fb, wm, bm, wb, bb, lmask = map(_c, (fm, fb, wm, bm, wb, bb, lmask))
+        N, D = fm.shape
+        B, L, _ = fb.shape
+        pm = fm.new_empty((B, L, L))
+        psea = fm.new_empty((3, B, L))
+        call("smin_score_map_fwd", stream(), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(wm), ptr(bm), ptr(wb), ptr(bb), ptr(lmask),
+             ptr(pm), ptr(psea))
+        ctx.save_for_backward(fm, fb, wm, wb, lmask, pm, psea)
+        ctx.layout = layout
+        return pm, psea
+
+    @staticmethod
+    def backward(ctx, dpm, dpsea):
+        fm, fb, wm, wb, lmask, pm, psea = ctx.saved_tensors
+        layout = ctx.layout
+        N, D = fm.shape
+        B, L, _ = fb.shape
+        dpm = _c(dpm) if dpm is not None else torch.zeros_like(pm)
+        dpsea = _c(dpsea) if dpsea is not None else torch.zeros_like(psea)
+        dfm, dfb = torch.empty_like(fm), torch.empty_like(fb)
+        dwm, dbm = torch.empty_like(wm), fm.new_empty((1,))
+        dwb, dbb = torch.empty_like(wb), fm.new_empty((3,))
+        _, wp, wn = _unit_ws(layout, 4, D, 4, 1, fm.device)
+        call("smin_score_map_bwd", stream(), ptr(dpm), ptr(dpsea), ptr(pm), ptr(psea), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D,
+             ptr(wm), ptr(wb), ptr(lmask), ptr(dfm), ptr(dfb), ptr(dwm), ptr(dbm), ptr(dwb), ptr(dbb), wp, wn)
+        return dfm, dfb, dwm, dbm, dwb, dbb, None, None
+
+
+def gemm_nt(a, b):
+    """C = A @ B^T on the library's fp32 MFMA engine (tests / bench roofline probe)."""
+    a, b = _c(a), _c(b)
+    M, K = a.shape
+    N = b.shape[0]
+    c = a.new_empty((M, N))
+    call("smin_gemm_nt", stream(), ptr(a), ptr(b), ptr(c), M, N, K)
+    return c

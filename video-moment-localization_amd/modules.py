@@ -1,0 +1,298 @@
+"""nn.Module surface of the reference's models.py, backed by the HIP kernels.
+
+Class names, constructor argument order/defaults, forward signatures, sub-module attribute names and
+therefore state_dict keys follow /root/reference/models.py (cited per class) so that an unmodified
+main.py / simpletest.py / config/*.yml can import this module in place of the reference's.  Parameters
+live in the same torch holders (Linear / Embedding / LSTM / Conv1d / Conv2d) created in the same order,
+so ``torch.manual_seed(s); SMIN(...)`` reproduces the reference's default initialisation.
+
+Inside ``SMIN.forward`` the L x L map lives in the packed valid-cell layout (cells.py); the dense
+(B, L, L, ...) tensors of the reference appear only at the stand-alone sub-module seams
+(``ContentUnit.forward`` etc.), which convert at the boundary and accept arbitrary dense inputs.
+Per-cell work runs in HIP (functional.py); O(B*Nq) / O(B*L*L*D) glue (query projections, the L x L
+boundary self-attention) and the backbone stay plain torch library calls.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .cells import CellLayout
+from .functional import BoundaryReduceFn, ContentUnitFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
+
+
+def _rows(mask):
+    """(B, N, 1) / (B, N) 0-1 mask -> float (B, N); unlike the reference's .squeeze() this is B=1 safe."""
+    return mask.reshape(mask.shape[0], -1).float()
+
+
+class VideoEncoder(nn.Module):
+    """reference models.py:7-36."""
+
+    def __init__(self, T=64, d=512, input_video_dim=1024, device='cpu'):
+        super().__init__()
+        self.T, self.d, self.d0, self.device = T, d, input_video_dim, device
+        self.ve = nn.Linear(self.d0, self.d)
+        self.pe = nn.Embedding(self.T, self.d)
+
+    def forward(self, video_features, video_mask):
+        vm = video_mask.float()
+        pos = torch.arange(video_mask.shape[1], device=video_features.device)
+        return self.ve(video_features) * vm + self.pe(pos).unsqueeze(0) * vm
+
+
+class QueryEncoder(nn.Module):
+    """reference models.py:38-64 (2-layer BiLSTM over packed word sequences)."""
+
+    def __init__(self, max_query_length=13, lstm_hidden_size=256):
+        super().__init__()
+        self.max_query_length, self.lstm_hidden_size = max_query_length, lstm_hidden_size
+        self.lstm = nn.LSTM(input_size=300, hidden_size=lstm_hidden_size, num_layers=2, bidirectional=True, batch_first=True)
+
+    def forward(self, query_features, query_mask):
+        B = query_features.shape[0]
+        length = query_mask.reshape(B, -1).sum(1)
+        packed = nn.utils.rnn.pack_padded_sequence(query_features, length.to('cpu'), batch_first=True, enforce_sorted=False)
+        out, _ = self.lstm(packed)
+        fw, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=self.max_query_length)
+        fw = fw.contiguous()
+        H = fw.shape[2] // 2
+        last = (length.long() - 1).view(B, 1, 1).expand(B, 1, H)
+        fs = torch.cat([fw[:, :, :H].gather(1, last).view(B, H), fw[:, 0, H:]], dim=1)
+        return fs, fw
+
+
+class Backbone(nn.Module):
+    """reference models.py:66-83."""
+
+    def __init__(self, T=64, d=512, input_video_dim=1024, max_query_length=13, lstm_hidden_size=256, device='cpu'):
+        super().__init__()
+        self.videoencoder = VideoEncoder(T, d, input_video_dim, device)
+        self.queryencoder = QueryEncoder(max_query_length, lstm_hidden_size)
+
+    def forward(self, video_features, video_mask, query_features, query_mask):
+        fv = self.videoencoder(video_features, video_mask)
+        fs, fw = self.queryencoder(query_features, query_mask)
+        return fv * fs.unsqueeze(1), fs, fw
+
+
+def compute_content_matrix(T, L, C):
+    """reference models.py:88-98, by index arithmetic instead of the triple Python loop.
+    Kept for API completeness; the kernels never materialise it."""
+    r = T // L
+    i = torch.arange(L).view(L, 1, 1, 1)
+    j = torch.arange(L).view(1, L, 1, 1)
+    c = torch.arange(C).view(1, 1, C, 1)
+    t = torch.arange(T).view(1, 1, 1, T)
+    n = (j - i + 1) * r
+    cs = torch.clamp(n // C, min=1)
+    start = i * r + c * cs
+    inside = (j >= i) & (c < torch.clamp(n, max=C)) & (t >= start) & (t < start + cs)
+    return inside.float() / cs.float()
+
+
+class ProposalGeneration(nn.Module):
+    """reference models.py:100-126.  ``self.Wc`` is not built (4 GiB at L=512); use compute_content_matrix."""
+
+    def __init__(self, T=64, L=16, C=4, device='cpu'):
+        super().__init__()
+        if T % L != 0:
+            raise ValueError("ProposalGeneration needs L | T (the reference breaks otherwise, SURVEY 8a-2)")
+        self.T, self.L, self.C, self.device = T, L, C, device
+
+    def forward_packed(self, f, layout):
+        return ProposalMapFn.apply(f, layout, self.T, self.L, self.C)
+
+    def forward(self, f, moment_mask):
+        layout = CellLayout.from_mask(moment_mask)
+        fc, fm, fb = self.forward_packed(f, layout)
+        return layout.unpack(fc), layout.unpack(fm), fb
+
+
+def _word_attention(W_q, W_k, query, key, value, mask, scale_dim):
+    q, k = W_q(query), W_k(key)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(scale_dim)
+    if mask is not None:
+        m = _rows(mask)
+        m = m.view(m.shape[0], *([1] * (s.dim() - 2)), m.shape[1])
+        s = (s * m).masked_fill(m == 0, -1e9)
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p, value), p
+
+
+class Attention(nn.Module):
+    """reference models.py:128-154 (boundary <-> word attention; O(B L Nq D), library GEMMs)."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D, self.attn_weights = D, None
+        self.W_q = nn.Linear(D, D)
+        self.W_k = nn.Linear(D, D)
+
+    def forward(self, query, key, value, mask=None):
+        out, _ = _word_attention(self.W_q, self.W_k, query, key, value, mask, self.D)
+        return out
+
+
+class BoundaryUnit(nn.Module):
+    """reference models.py:156-196."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+        self.attn_layer = Attention(D)
+
+    def forward_packed(self, f_b, f_w, f_s, fm, query_mask, length_mask, layout):
+        lm = length_mask.float()
+        lcol = lm.unsqueeze(-1)
+        baq = self.attn_layer(f_b, f_w, f_w, query_mask) * lcol
+        bq = f_b * (baq + f_s.unsqueeze(1))
+        z = torch.bmm(bq, bq.transpose(1, 2)) / math.sqrt(self.D)
+        lrow = lm.unsqueeze(1)
+        A = torch.softmax((z * lrow).masked_fill(lrow == 0, -1e9), dim=-1) * lcol
+        f_bb = torch.bmm(A, f_b) * lcol
+        f_bm = BoundaryReduceFn.apply(A, fm, f_s, layout)          # HIP: gated row reduction of the map
+        return f_bb + f_b + f_bm
+
+    def forward(self, f_b, f_w, f_s, f_m, query_mask, length_mask):
+        B, L = f_m.shape[:2]
+        layout = CellLayout.all_cells(torch.ones(B, L, L, dtype=torch.bool, device=f_m.device))
+        return self.forward_packed(f_b, f_w, f_s, layout.pack(f_m), query_mask, length_mask, layout)
+
+
+class ContentAttention(nn.Module):
+    """reference models.py:198-226.  Inside ContentUnit this attention is fused into the HIP content
+    kernels (W_q/W_k folded per sample); this stand-alone forward serves the 5-D module seam only."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D, self.attn_weights = D, None
+        self.W_q = nn.Linear(D, D)
+        self.W_k = nn.Linear(D, D)
+
+    def forward(self, query, key, value, mask=None):
+        B = query.shape[0]
+        q = query.reshape(B, -1, query.shape[-1])
+        out, _ = _word_attention(self.W_q, self.W_k, q, key, value, mask, self.D)
+        return out.reshape(query.shape[:-1] + (value.shape[-1],))
+
+
+class ContentUnit(nn.Module):
+    """reference models.py:228-276."""
+
+    def __init__(self, D, dl):
+        super().__init__()
+        self.D, self.dl = D, dl
+        self.linear_c_hat = nn.Linear(D, dl)
+        self.linear_w_hat = nn.Linear(D, dl)
+        self.linear_s_hat = nn.Linear(D, dl)
+        self.linear_c = nn.Linear(dl, D)
+        self.attn_layer = ContentAttention(dl)
+
+    def forward_packed(self, fc, fm, f_w, f_s, query_mask, layout):
+        qm = _rows(query_mask)
+        what = self.linear_w_hat(f_w) * qm.unsqueeze(-1)
+        shat = self.linear_s_hat(f_s)
+        kb = self.attn_layer.W_k(what)
+        # W_q(c_hat) . kb^T == c_hat . (kb W_q.weight)^T + kb . W_q.bias : the per-cell dl x dl projection folds away
+        Mq = torch.matmul(kb, self.attn_layer.W_q.weight)
+        uq = torch.matmul(kb, self.attn_layer.W_q.bias)
+        return ContentUnitFn.apply(fc, fm, f_s, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
+                                   self.linear_c.weight, self.linear_c.bias, layout)
+
+    def forward(self, f_c, f_w, f_s, f_m, query_mask, moment_mask):
+        layout = CellLayout.all_cells(moment_mask)
+        out, _ = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_w, f_s, query_mask, layout)
+        return layout.unpack(out)
+
+
+class MomentUnit(nn.Module):
+    """reference models.py:278-303."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+        self.conv_layer_fb = nn.Conv2d(D, D, 1)
+        self.conv_layer_fc = nn.Conv2d(D, D, 1)
+
+    def forward_packed(self, fcmean, fm, f_b, layout):
+        D = self.D
+        Wcat = torch.cat([self.conv_layer_fb.weight.view(D, D), self.conv_layer_fc.weight.view(D, D)], dim=1)
+        bcat = self.conv_layer_fb.bias + self.conv_layer_fc.bias
+        return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)
+
+    def forward(self, f_c, f_m, f_b, moment_mask):
+        layout = CellLayout.all_cells(moment_mask)
+        mu = self.forward_packed(layout.pack(f_c).mean(dim=1), layout.pack(f_m), f_b, layout)
+        return layout.unpack(mu)
+
+
+class SMI(nn.Module):
+    """reference models.py:305-322: content and boundary units read the layer inputs, the moment unit their outputs."""
+
+    def __init__(self, D, dl):
+        super().__init__()
+        self.D, self.dl = D, dl
+        self.content_unit = ContentUnit(D, dl)
+        self.boundary_unit = BoundaryUnit(D)
+        self.moment_unit = MomentUnit(D)
+
+    def forward_packed(self, fc, fm, f_b, f_w, f_s, query_mask, length_mask, layout):
+        cu, cumean = self.content_unit.forward_packed(fc, fm, f_w, f_s, query_mask, layout)
+        bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, fm, query_mask, length_mask, layout)
+        mu = self.moment_unit.forward_packed(cumean, fm, bu, layout)
+        return cu, mu, bu
+
+    def forward(self, f_c, f_m, f_b, f_w, f_s, query_mask, length_mask, moment_mask):
+        layout = CellLayout.all_cells(moment_mask)
+        cu, mu, bu = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_b, f_w, f_s, query_mask, length_mask, layout)
+        return layout.unpack(cu), layout.unpack(mu), bu
+
+
+class Localization(nn.Module):
+    """reference models.py:324-344."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.conv_layer_pm = nn.Conv2d(D, 1, 1)
+        self.conv_layer_ps = nn.Conv1d(D, 1, 1)
+        self.conv_layer_pe = nn.Conv1d(D, 1, 1)
+        self.conv_layer_pa = nn.Conv1d(D, 1, 1)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward_packed(self, fm, f_b, length_mask, layout):
+        D = f_b.shape[-1]
+        heads = (self.conv_layer_ps, self.conv_layer_pe, self.conv_layer_pa)
+        wb = torch.stack([h.weight.view(D) for h in heads])
+        bb = torch.cat([h.bias for h in heads])
+        pm, psea = ScoreMapFn.apply(fm, f_b, self.conv_layer_pm.weight.view(D), self.conv_layer_pm.bias, wb, bb,
+                                    length_mask.float(), layout)
+        return pm, psea[0], psea[1], psea[2]
+
+    def forward(self, f_m, f_b, length_mask, moment_mask):
+        layout = CellLayout.all_cells(moment_mask)
+        return self.forward_packed(layout.pack(f_m), f_b, length_mask, layout)
+
+
+class SMIN(nn.Module):
+    """reference models.py:346-377 -- the drop-in boundary (ctor called positionally from main.py:71)."""
+
+    def __init__(self, T, L, C, D, dl, num_smi_layers, input_video_dim, max_query_length, lstm_hidden_size, device='cpu'):
+        super().__init__()
+        self.T, self.L, self.C, self.D, self.dl = T, L, C, D, dl
+        self.num_smi_layers, self.input_video_dim = num_smi_layers, input_video_dim
+        self.max_query_length, self.lstm_hidden_size, self.device = max_query_length, lstm_hidden_size, device
+        if D != 2 * lstm_hidden_size:
+            raise ValueError("SMIN needs D == 2 * lstm_hidden_size (reference models.py:62,81)")
+        self.backbone = Backbone(T, D, input_video_dim, max_query_length, lstm_hidden_size, device)
+        self.pgm = ProposalGeneration(T, L, C, device)
+        self.smis = nn.ModuleList([SMI(D, dl) for _ in range(num_smi_layers)])
+        self.localization = Localization(D)
+
+    def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
+        f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
+        layout = CellLayout.from_mask(moment_mask)                 # work is driven by moment_mask (SURVEY 8a-0 caveat)
+        fc, fm, fb = self.pgm.forward_packed(f, layout)
+        for smi in self.smis:
+            fc, fm, fb = smi.forward_packed(fc, fm, fb, fw, fs, query_mask, length_mask, layout)
+        return self.localization.forward_packed(fm, fb, length_mask, layout)

@@ -1,0 +1,37 @@
+"""Caller-side pieces of the reference that the train step needs: the loss and the
+R@n/IoU metric, restated so that the unmodified training loop becomes runnable.  Plain torch; they run
+on whatever device the scores live on."""
+import torch
+import torch.nn.functional as F
+
+
+def bce_loss(p, y, s, mask):
+    """reference main.py:89-108.  The reference builds BCELoss(reduction=None), which raises on every torch
+    release; the evident intent -- element-wise loss, masked, per-sample mean, batch mean -- is what runs here."""
+    yf = y.to(p.dtype)
+    mk = mask.to(p.dtype)
+    if s is not None:
+        loss = (F.binary_cross_entropy(p, yf, weight=s * yf, reduction="none")
+                + F.binary_cross_entropy(1 - p, 1 - yf, weight=(1 - s) * (1 - yf), reduction="none"))
+    else:
+        loss = F.binary_cross_entropy(p, yf, reduction="none")
+    loss = loss * mk
+    dims = (1, 2) if mask.dim() == 3 else (1,)
+    return (loss.sum(dim=dims) / mk.sum(dim=dims)).mean()
+
+
+def loss_fn(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask):
+    """reference main.py:110-116: L_m + L_s + L_e + 0.5 L_a."""
+    return (bce_loss(pm, ym, sm, moment_mask) + bce_loss(ps, ys, ss, length_mask)
+            + bce_loss(pe, ye, se, length_mask) + 0.5 * bce_loss(pa, ya, None, length_mask))
+
+
+def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
+    """reference utils.py:10-31 with a single host sync (the reference syncs once per (n, m) pair)."""
+    score = pm * torch.sqrt(ps.unsqueeze(2)) * torch.sqrt(pe.unsqueeze(1)) * moment_mask
+    B = score.shape[0]
+    _, top = score.reshape(B, -1).topk(k=max(n), dim=1)
+    ious = torch.gather(sm.reshape(B, -1), 1, top)
+    counts = torch.stack([((ious[:, :n_] > m_).sum(dim=1) > 0).sum() for n_ in n for m_ in m]).tolist()
+    keys = [f"R@{n_}, IoU={m_}" for n_ in n for m_ in m]
+    return {k: float(v) for k, v in zip(keys, counts)}
