@@ -49,42 +49,49 @@ int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, cons
                           const int32_t* cells, const int32_t* cellmap, int N, int B, int T, int L, int C, int D,
                           float* df, void* ws, size_t ws_bytes);
 
+/* ---- Gated moment feature shared by ContentUnit (models.py:272-274) and BoundaryUnit (models.py:191):
+ *   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]          hbar [N][D]
+ * backward: dfm [N][D], dfs [B][D] from dhbar (the sum of both consumers' gradients). */
+int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar);
+int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, const float* fs, const int32_t* row_ptr,
+                  int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes);
+
 /* ---- ContentUnit.forward (models.py:242-276) incl. ContentAttention.forward (models.py:207-226).
  * Query-side per-sample operands are prepared by the host (O(B*Nq*dl) work):
  *   what [B][Nq][dl] = linear_w_hat(f_w) * query_mask          shat [B][dl] = linear_s_hat(f_s)
  *   Mq   [B][Nq][dl] = W_k(what) @ W_q.weight                   uq   [B][Nq] = W_k(what) @ W_q.bias
  *   (so that  W_q(c_hat) . W_k(what)^T  ==  c_hat . Mq^T + uq  -- the per-cell dl x dl projection folds away)
- *   qmask [B][Nq] fp32 0/1.
+ *   qmask [B][Nq] fp32 0/1;  hbar from smin_gate_fwd.
  * Outputs: fc_out [N][C][D], fcmean [N][D] = mean_c fc_out (consumed by the moment unit);
  * saved for backward: chat [N*C][dl], cchat [N*C][dl]. */
-int smin_content_unit_fwd(void* stream, const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
+int smin_content_unit_fwd(void* stream, const float* fc, const float* hbar, const int32_t* cells, const int32_t* row_ptr,
                           int N, int B, int L, int C, int D, int dl, int Nq,
-                          const float* fs, const float* Wch, const float* bch, const float* Mq, const float* uq,
+                          const float* Wch, const float* bch, const float* Mq, const float* uq,
                           const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
                           float* fc_out, float* fcmean, float* chat, float* cchat);
 /* Backward.  dfc_out may be NULL (last layer: only the moment unit consumes fc_out, through fcmean).
  * WcT [dl][D] and WchT [D][dl] are transposed copies of the weights.
- * Gradients: dfc [N][C][D], dfm [N][D] (gate path only), dfs [B][D] (gate path only), dWch [dl][D], dbch [dl],
- * dMq [B][Nq][dl], duq [B][Nq], dwhat [B][Nq][dl], dshat [B][dl], dWc [D][dl], dbc [D]. */
+ * Gradients: dfc [N][C][D], dhbar [N][D], dWch [dl][D], dbch [dl], dMq [B][Nq][dl], duq [B][Nq],
+ * dwhat [B][Nq][dl], dshat [B][dl], dWc [D][dl], dbc [D]. */
 int smin_content_unit_bwd(void* stream, const float* dfc_out, const float* dfcmean,
-                          const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
+                          const float* fc, const int32_t* cells, const int32_t* row_ptr,
                           int N, int B, int L, int C, int D, int dl, int Nq,
-                          const float* fs, const float* Wch, const float* WchT, const float* Mq, const float* uq,
+                          const float* WchT, const float* Mq, const float* uq,
                           const float* what, const float* shat, const float* qmask, const float* WcT,
                           const float* chat, const float* cchat,
-                          float* dfc, float* dfm, float* dfs, float* dWch, float* dbch, float* dMq, float* duq,
+                          float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
                           float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes);
 
 /* ---- BoundaryUnit.forward, the map-sized part (models.py:190-194):
- *   fbm[b,i,:] = sum_j A_b[b,i,j] * sigmoid(f_m[(b,i,j)] * f_s[b]) * f_m[(b,i,j)]
+ *   fbm[b,i,:] = sum_j A_b[b,i,j] * hbar[(b,i,j),:]
  * A_b [B][L][L] comes from the L x L boundary self-attention (models.py:164-188), which the host runs
  * as plain library GEMMs.  fbm [B][L][D]. */
-int smin_boundary_reduce_fwd(void* stream, const float* Ab, const float* fm, const float* fs, const int32_t* cells,
+int smin_boundary_reduce_fwd(void* stream, const float* Ab, const float* hbar, const int32_t* cells,
                              const int32_t* row_ptr, int N, int B, int L, int D, float* fbm);
-/* dAb [B][L][L] (zero where no cell), dfm [N][D], dfs [B][D]. */
-int smin_boundary_reduce_bwd(void* stream, const float* dfbm, const float* Ab, const float* fm, const float* fs,
+/* dAb [B][L][L] (zero where no cell), dhbar [N][D]. */
+int smin_boundary_reduce_bwd(void* stream, const float* dfbm, const float* Ab, const float* hbar,
                              const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int D,
-                             float* dAb, float* dfm, float* dfs, void* ws, size_t ws_bytes);
+                             float* dAb, float* dhbar);
 
 /* ---- MomentUnit.forward (models.py:288-303): two 1x1 convs fused into one K = 2D contraction
  *   mu[n,:] = m * ( [fb[b,i]*fb[b,j] | fcmean[n]] @ Wcat^T + bcat ) + fm[n,:]

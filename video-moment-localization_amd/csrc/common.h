@@ -18,6 +18,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// chunking of each sample's cell range over workgroups: <= 64 chunks per sample, >= 32 cells each
+static inline void chunking(int L, int* cells_per_chunk, int* max_chunks)
+{
+    const int max_cells = L * L;
+    int cpc = cdiv(max_cells, 64);
+    if (cpc < 32) cpc = 32;
+    *cells_per_chunk = cpc;
+    *max_chunks = cdiv(max_cells, cpc);
+}
+
 // One packed cell of the L x L proposal map: (sample, start snippet, end snippet, mask).
 struct Cell { int b, i, j, m; };
 

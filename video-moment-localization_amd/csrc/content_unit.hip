@@ -13,66 +13,98 @@
 
 namespace smin {
 
-// ------------------------------------------------------------------ epilogues
+// ------------------------------------------------------------------ epilogues (see gemm.h: tile protocol)
 struct EpBiasMask {                 // chat[row][col] = (acc + bias[col]) * m[row / C]
-    const float* bias; const int* cells; float* out; int M, N, C;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
-        const float b = bias[col];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + q;
-            if (row < M) out[(size_t)row * N + col] = (v[q] + b) * (float)cells[4 * (size_t)(row / C) + 3];
-        }
+    const float* bias; const int* cells; float* out; int C;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+            const float m = (float)cells[4 * (size_t)(row / C) + 3];
+            stg4(out + (size_t)row * N + col, f4scale(f4add(v, ldg4(bias + col)), m));
+        });
     }
 };
 
-struct EpContentOut {               // (acc + bc) * m + fc + sigmoid(fm * fs) * fm      (models.py:269-276)
-    const float* bc; const int* cells; const float* fc; const float* fm; const float* fs; float* out; int M, N, C;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
-        const float b = bc[col];
+// out = (acc + bc) * m + fc + hbar[n]      (models.py:269-276; hbar = sigmoid(fm*fs)*fm from gate.hip)
+struct EpContentOut {               // any C
+    const float* bc; const int* cells; const float* fc; const float* hbar; float* out; int C;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+            const int n = row / C;
+            const float m = (float)cells[4 * (size_t)n + 3];
+            const float4 o = f4add(f4add(f4scale(f4add(v, ldg4(bc + col)), m), ldg4(fc + (size_t)row * N + col)), ldg4(hbar + (size_t)n * N + col));
+            stg4(out + (size_t)row * N + col, o);
+        });
+    }
+};
+struct EpContentOut4 {              // C == 4: one lane owns the 4 clips of a cell -> also emits fcmean = mean_c out
+    const float* bc; const int* cells; const float* fc; const float* hbar; float* out; float* fcmean;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + q;
-            if (row < M) {
-                const int n = row / C;
-                const int4 cl = *reinterpret_cast<const int4*>(cells + 4 * (size_t)n);
-                const float x = fm[(size_t)n * N + col];
-                const float g = 1.0f / (1.0f + expf(-x * fs[(size_t)cl.x * N + col]));
-                out[(size_t)row * N + col] = (v[q] + b) * (float)cl.w + fc[(size_t)row * N + col] + g * x;
+        for (int it = 0; it < 4; ++it) {
+            const int idx = t + 256 * it, cl = idx >> 5, c4 = (idx & 31) * 4;
+            const int n = (row_base >> 2) + cl, col = col_base + c4;
+            if (4 * n < M && col < N) {
+                const float m = (float)cells[4 * (size_t)n + 3];
+                const float4 b4 = ldg4(bc + col), hb = ldg4(hbar + (size_t)n * N + col);
+                float4 sum = f4zero();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t o = ((size_t)n * 4 + c) * N + col;
+                    const float4 v = ldg4(Cs + (cl * 4 + c) * GEMM_LDC + c4);
+                    const float4 r = f4add(f4add(f4scale(f4add(v, b4), m), ldg4(fc + o)), hb);
+                    stg4(out + o, r);
+                    sum = f4add(sum, r);
+                }
+                stg4(fcmean + (size_t)n * N + col, f4scale(sum, 0.25f));
             }
         }
     }
 };
 
 struct EpPlain {
-    float* out; int M, N;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (row0 + q < M) out[(size_t)(row0 + q) * N + col] = v[q];
+    float* out;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
     }
 };
 
-struct EpAddDout {                  // dfc = acc + dfc_out + dfcmean / C   (residual path, un-masked)
-    const float* dfc_out; const float* dmean; float* out; int M, N, C; float invC;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
+// dfc = acc + dfc_out + dfcmean / C   (residual path, un-masked)
+template <bool HAS_DFC>
+struct EpAddDout {                  // any C
+    const float* dfc_out; const float* dmean; float* out; int C; float invC;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+            float4 r = f4fma(ldg4(dmean + (size_t)(row / C) * N + col), invC, v);
+            if (HAS_DFC) r = f4add(r, ldg4(dfc_out + (size_t)row * N + col));
+            stg4(out + (size_t)row * N + col, r);
+        });
+    }
+};
+template <bool HAS_DFC>
+struct EpAddDout4 {                 // C == 4: also emits dhbar[n] = sum_c dout[n,c] (gradient of the gate term)
+    const float* dfc_out; const float* dmean; float* out; float* dhbar;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + q;
-            if (row < M) {
-                float r = v[q] + dmean[(size_t)(row / C) * N + col] * invC;
-                if (dfc_out) r += dfc_out[(size_t)row * N + col];
-                out[(size_t)row * N + col] = r;
+        for (int it = 0; it < 4; ++it) {
+            const int idx = t + 256 * it, cl = idx >> 5, c4 = (idx & 31) * 4;
+            const int n = (row_base >> 2) + cl, col = col_base + c4;
+            if (4 * n < M && col < N) {
+                const float4 dm = ldg4(dmean + (size_t)n * N + col);
+                float4 sum = dm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t o = ((size_t)n * 4 + c) * N + col;
+                    float4 r = f4fma(dm, 0.25f, ldg4(Cs + (cl * 4 + c) * GEMM_LDC + c4));
+                    if (HAS_DFC) { const float4 d = ldg4(dfc_out + o); r = f4add(r, d); sum = f4add(sum, d); }
+                    stg4(out + o, r);
+                }
+                stg4(dhbar + (size_t)n * N + col, sum);
             }
         }
     }
 };
 
-// ------------------------------------------------------------------ mean over clips
+// ------------------------------------------------------------------ small element-wise helpers (C != 4 only)
 __global__ void clip_mean_kernel(const float* __restrict__ fc, float* __restrict__ out, int N, int C, int D4, float invC)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +113,18 @@ __global__ void clip_mean_kernel(const float* __restrict__ fc, float* __restrict
     float4 s = f4zero();
     for (int c = 0; c < C; ++c) s = f4add(s, ldg4(fc + ((n * C + c) * D4 + d4) * 4));
     stg4(out + idx * 4, f4scale(s, invC));
+}
+
+// dhbar[n] = dfcmean[n] + sum_c dfc_out[n,c]
+__global__ void dout_sum_kernel(const float* __restrict__ dfc_out, const float* __restrict__ dmean, float* __restrict__ out, int N, int C, int D4)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * D4) return;
+    const size_t n = idx / D4; const int d4 = (int)(idx % D4);
+    float4 s = ldg4(dmean + idx * 4);
+    if (dfc_out)
+        for (int c = 0; c < C; ++c) s = f4add(s, ldg4(dfc_out + ((n * C + c) * D4 + d4) * 4));
+    stg4(out + idx * 4, s);
 }
 
 // ------------------------------------------------------------------ attention core
@@ -428,67 +472,7 @@ __global__ void content_attn_reduce_kernel(const float* __restrict__ slab, const
     else { const int w = x - 2 * NQP * dl - dl; if (w < Nq) duq[(size_t)b * Nq + w] = s; }
 }
 
-// Gate path of the output (models.py:272-276):  out += sigmoid(fm*fs)*fm  broadcast over clips.
-//   dsum = sum_c dout[n,c,:] ; dfm = dsum * (g + fm*g*(1-g)*fs) ; dfs[b] += dsum * fm^2 * g*(1-g)
-// grid (chunks, B), 128 threads, each thread owns float4 columns d4 = t, t+128, ...; partial[b][chunk][D].
-__global__ __launch_bounds__(128)
-void content_gate_bwd_kernel(const float* __restrict__ dfc_out, const float* __restrict__ dmean, const float* __restrict__ fm,
-                             const float* __restrict__ fs, const int* __restrict__ row_ptr, int L, int C, int D,
-                             int cells_per_chunk, int max_chunks, float* __restrict__ dfm, float* __restrict__ partial)
-{
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
-    const int n_begin = s0 + chunk * cells_per_chunk;
-    if (n_begin >= s1) return;
-    const int n_end = min(s1, n_begin + cells_per_chunk);
-    for (int d = threadIdx.x * 4; d < D; d += 512) {
-        const float4 s4 = ldg4(fs + (size_t)b * D + d);
-        float4 acc = f4zero();
-        for (int n = n_begin; n < n_end; ++n) {
-            float4 ds = ldg4(dmean + (size_t)n * D + d);          // sum_c dmean/C = dmean
-            if (dfc_out)
-                for (int c = 0; c < C; ++c) ds = f4add(ds, ldg4(dfc_out + ((size_t)n * C + c) * D + d));
-            const float4 x = ldg4(fm + (size_t)n * D + d);
-            float4 o;
-#define GATE1(F)                                                                  \
-            {                                                                     \
-                const float g = 1.0f / (1.0f + expf(-x.F * s4.F));                \
-                const float gg = g * (1.0f - g);                                  \
-                o.F = ds.F * (g + x.F * gg * s4.F);                               \
-                acc.F = fmaf(ds.F, x.F * x.F * gg, acc.F);                        \
-            }
-            GATE1(x) GATE1(y) GATE1(z) GATE1(w)
-#undef GATE1
-            stg4(dfm + (size_t)n * D + d, o);
-        }
-        stg4(partial + ((size_t)b * max_chunks + chunk) * D + d, acc);
-    }
-}
-
-__global__ void sample_partial_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ row_ptr, int L, int D,
-                                             int cells_per_chunk, int max_chunks, float* __restrict__ out)
-{
-    const int b = blockIdx.y;
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
-    const int ncell = row_ptr[(b + 1) * L] - row_ptr[b * L];
-    const int nch = (ncell + cells_per_chunk - 1) / cells_per_chunk;
-    float s = 0.f;
-    for (int k = 0; k < nch; ++k) s += partial[((size_t)b * max_chunks + k) * D + d];
-    out[(size_t)b * D + d] = s;
-}
-
 static inline int nq_pad(int Nq) { return Nq <= 8 ? 8 : Nq <= 16 ? 16 : Nq <= 24 ? 24 : 32; }
-
-// chunking of each sample's cell range over workgroups: <= 64 chunks per sample, >= 32 cells each
-static inline void chunking(int L, int* cells_per_chunk, int* max_chunks)
-{
-    const int max_cells = L * L;
-    int cpc = cdiv(max_cells, 64);
-    if (cpc < 32) cpc = 32;
-    *cells_per_chunk = cpc;
-    *max_chunks = cdiv(max_cells, cpc);
-}
 
 template <int C, int DPL>
 static int launch_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L,
@@ -534,17 +518,17 @@ static int dispatch_attn_bwd_nq(int NQP, hipStream_t st, const float* chat, cons
 
 using namespace smin;
 
-extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
-                                          int N, int B, int L, int C, int D, int dl, int Nq,
-                                          const float* fs, const float* Wch, const float* bch, const float* Mq, const float* uq,
-                                          const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
-                                          float* fc_out, float* fcmean, float* chat, float* cchat)
+extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float* hbar, const int32_t* cells, const int32_t* row_ptr,
+                                     int N, int B, int L, int C, int D, int dl, int Nq,
+                                     const float* Wch, const float* bch, const float* Mq, const float* uq,
+                                     const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
+                                     float* fc_out, float* fcmean, float* chat, float* cchat)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     SMIN_REQUIRE(D % 4 == 0 && dl % 4 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     const int M = N * C;
-    int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, M, dl, C}, M, dl, D);
+    int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, C}, M, dl, D);
     if (rc) return rc;
     const int DPL = cdiv(dl, 64);
 #define ATTN_FWD(CC, DD) rc = launch_attn_fwd<CC, DD>(st, chat, cells, row_ptr, B, L, Mq, uq, what, shat, qmask, cchat, dl, Nq)
@@ -553,7 +537,9 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
     else { if (DPL == 1) ATTN_FWD(2, 1); else ATTN_FWD(2, 2); }
 #undef ATTN_FWD
     if (rc) return rc;
-    rc = launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpContentOut{bc, cells, fc, fm, fs, fc_out, M, D, C}, M, D, dl);
+    if (C == 4)
+        return launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpContentOut4{bc, cells, fc, hbar, fc_out, fcmean}, M, D, dl);
+    rc = launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpContentOut{bc, cells, fc, hbar, fc_out, C}, M, D, dl);
     if (rc) return rc;
     const int D4 = D / 4;
     const size_t tot = (size_t)N * D4;
@@ -562,24 +548,20 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
     return 0;
 }
 
-extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const float* dfcmean,
-                                          const float* fc, const float* fm, const int32_t* cells, const int32_t* row_ptr,
-                                          int N, int B, int L, int C, int D, int dl, int Nq,
-                                          const float* fs, const float* Wch, const float* WchT, const float* Mq, const float* uq,
-                                          const float* what, const float* shat, const float* qmask, const float* WcT,
-                                          const float* chat, const float* cchat,
-                                          float* dfc, float* dfm, float* dfs, float* dWch, float* dbch, float* dMq, float* duq,
-                                          float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes)
+template <bool HAS_DFC>
+static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const float* dfcmean,
+                                 const float* fc, const int32_t* cells, const int32_t* row_ptr,
+                                 int N, int B, int L, int C, int D, int dl, int Nq,
+                                 const float* WchT, const float* Mq, const float* uq,
+                                 const float* what, const float* shat, const float* qmask, const float* WcT,
+                                 const float* chat, const float* cchat,
+                                 float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
+                                 float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes)
 {
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    SMIN_REQUIRE(D % 4 == 0 && dl % 4 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
-    if (N == 0) return 0;
-    (void)Wch;
     const int M = N * C;
     const int NQP = nq_pad(Nq);
     int cpc, mc; chunking(L, &cpc, &mc);
     const float invC = 1.0f / C;
-    // workspace carve
     float* w = reinterpret_cast<float*>(ws);
     size_t off = 0;
     auto take = [&](size_t n) { float* p = w + off; off += (n + 3) & ~(size_t)3; return p; };
@@ -590,14 +572,14 @@ extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const f
     float* slab2 = take((size_t)sp2 * dl * D); float* bslab2 = take((size_t)sp2 * dl);
     const size_t attn_slab_sz = (size_t)2 * NQP * dl + dl + 32;
     float* aslab = take((size_t)B * mc * 4 * attn_slab_sz);
-    float* gpart = take((size_t)B * mc * D);
     SMIN_REQUIRE(off * sizeof(float) <= ws_bytes);
+    const DoutEffMat<true, HAS_DFC> dout{dfc_out, dfcmean, cells, C, D, invC};
 
     // (a) dcchat = (dout * m) @ Wc          [M, dl], contraction over D
-    int rc = launch_gemm_nt(st, DoutEffMat<true>{dfc_out, dfcmean, cells, C, D, invC}, PlainMat{WcT, D}, EpPlain{dcchat, M, dl}, M, dl, D);
+    int rc = launch_gemm_nt(st, dout, PlainMat{WcT, D}, EpPlain{dcchat}, M, dl, D);
     if (rc) return rc;
     // (b) dWc[D, dl] = (dout*m)^T @ cchat ; dbc = colsum(dout*m)
-    rc = launch_gemm_tn(st, DoutEffMat<true>{dfc_out, dfcmean, cells, C, D, invC}, PlainMat{cchat, dl}, slab1, bslab1, M, D, dl, sp1);
+    rc = launch_gemm_tn(st, dout, PlainMat{cchat, dl}, slab1, bslab1, M, D, dl, sp1);
     if (rc) return rc;
     rc = launch_reduce_slabs(st, slab1, dWc, D * dl, sp1); if (rc) return rc;
     rc = launch_reduce_slabs(st, bslab1, dbc, D, sp1); if (rc) return rc;
@@ -612,18 +594,40 @@ extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const f
     hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv((int)attn_slab_sz, 256), B), dim3(256), 0, st, aslab, row_ptr, L,
                        dl, Nq, NQP, cpc, mc, dMq, dwhat, dshat, duq);
     SMIN_LAUNCH_CHECK();
-    // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl
-    rc = launch_gemm_nt(st, PlainMat{dchat, dl}, PlainMat{WchT, dl}, EpAddDout{dfc_out, dfcmean, dfc, M, D, C, invC}, M, D, dl);
-    if (rc) return rc;
+    // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl;  dhbar = sum_c dout (gate term)
+    if (C == 4) {
+        rc = launch_gemm_nt(st, PlainMat{dchat, dl}, PlainMat{WchT, dl}, EpAddDout4<HAS_DFC>{dfc_out, dfcmean, dfc, dhbar}, M, D, dl);
+        if (rc) return rc;
+    } else {
+        rc = launch_gemm_nt(st, PlainMat{dchat, dl}, PlainMat{WchT, dl}, EpAddDout<HAS_DFC>{dfc_out, dfcmean, dfc, C, invC}, M, D, dl);
+        if (rc) return rc;
+        const size_t tot = (size_t)N * (D / 4);
+        hipLaunchKernelGGL(dout_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dfc_out, dfcmean, dhbar, N, C, D / 4);
+        SMIN_LAUNCH_CHECK();
+    }
     // (e) dWch[dl, D] = dchat^T @ fc ; dbch = colsum(dchat)
     rc = launch_gemm_tn(st, PlainMat{dchat, dl}, PlainMat{fc, D}, slab2, bslab2, M, dl, D, sp2);
     if (rc) return rc;
     rc = launch_reduce_slabs(st, slab2, dWch, dl * D, sp2); if (rc) return rc;
     rc = launch_reduce_slabs(st, bslab2, dbch, dl, sp2); if (rc) return rc;
-    // (f) gate path
-    hipLaunchKernelGGL(content_gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dfc_out, dfcmean, fm, fs, row_ptr, L, C, D, cpc, mc, dfm, gpart);
-    SMIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sample_partial_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, gpart, row_ptr, L, D, cpc, mc, dfs);
-    SMIN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const float* dfcmean,
+                                     const float* fc, const int32_t* cells, const int32_t* row_ptr,
+                                     int N, int B, int L, int C, int D, int dl, int Nq,
+                                     const float* WchT, const float* Mq, const float* uq,
+                                     const float* what, const float* shat, const float* qmask, const float* WcT,
+                                     const float* chat, const float* cchat,
+                                     float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
+                                     float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SMIN_REQUIRE(D % 4 == 0 && dl % 4 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    if (N == 0) return 0;
+    if (dfc_out)
+        return content_unit_bwd_impl<true>(st, dfc_out, dfcmean, fc, cells, row_ptr, N, B, L, C, D, dl, Nq, WchT, Mq, uq, what, shat, qmask,
+                                           WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes);
+    return content_unit_bwd_impl<false>(st, nullptr, dfcmean, fc, cells, row_ptr, N, B, L, C, D, dl, Nq, WchT, Mq, uq, what, shat, qmask,
+                                        WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes);
 }

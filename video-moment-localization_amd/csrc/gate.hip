@@ -1,0 +1,96 @@
+// Gated moment feature shared by the content and boundary units (reference models.py:191, 272-274):
+//   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]
+// computed once per layer (element-wise, HBM-bound) instead of inside every consumer.
+#include "common.h"
+#include "smin_hip.h"
+
+namespace smin {
+
+__global__ void gate_fwd_kernel(const float* __restrict__ fm, const float* __restrict__ fs, const int* __restrict__ cells,
+                                int N, int D4, float* __restrict__ hbar)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * D4) return;
+    const size_t n = idx / D4; const int d4 = (int)(idx % D4);
+    const int b = cells[4 * n];
+    const float4 x = ldg4(fm + idx * 4), s = ldg4(fs + ((size_t)b * D4 + d4) * 4);
+    stg4(hbar + idx * 4, make_float4(x.x / (1.0f + expf(-x.x * s.x)), x.y / (1.0f + expf(-x.y * s.y)),
+                                     x.z / (1.0f + expf(-x.z * s.z)), x.w / (1.0f + expf(-x.w * s.w))));
+}
+
+// dfm = dh * (g + fm*g*(1-g)*fs) ; partial[b][chunk][:] = sum over the chunk's cells of dh * fm^2 * g*(1-g)
+// grid (chunks, B), 128 threads, float4 columns.
+__global__ __launch_bounds__(128)
+void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ fm, const float* __restrict__ fs,
+                     const int* __restrict__ row_ptr, int L, int D, int cells_per_chunk, int max_chunks,
+                     float* __restrict__ dfm, float* __restrict__ partial)
+{
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
+    const int n_begin = s0 + chunk * cells_per_chunk;
+    if (n_begin >= s1) return;
+    const int n_end = min(s1, n_begin + cells_per_chunk);
+    for (int d = threadIdx.x * 4; d < D; d += 512) {
+        const float4 s4 = ldg4(fs + (size_t)b * D + d);
+        float4 acc = f4zero();
+        for (int n = n_begin; n < n_end; ++n) {
+            const float4 ds = ldg4(dh + (size_t)n * D + d);
+            const float4 x = ldg4(fm + (size_t)n * D + d);
+            float4 o;
+#define GATE1(F)                                                                  \
+            {                                                                     \
+                const float g = 1.0f / (1.0f + expf(-x.F * s4.F));                \
+                const float gg = g * (1.0f - g);                                  \
+                o.F = ds.F * (g + x.F * gg * s4.F);                               \
+                acc.F = fmaf(ds.F, x.F * x.F * gg, acc.F);                        \
+            }
+            GATE1(x) GATE1(y) GATE1(z) GATE1(w)
+#undef GATE1
+            stg4(dfm + (size_t)n * D + d, o);
+        }
+        stg4(partial + ((size_t)b * max_chunks + chunk) * D + d, acc);
+    }
+}
+
+__global__ void sample_partial_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ row_ptr, int L, int D,
+                                             int cells_per_chunk, int max_chunks, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const int ncell = row_ptr[(b + 1) * L] - row_ptr[b * L];
+    const int nch = (ncell + cells_per_chunk - 1) / cells_per_chunk;
+    float s = 0.f;
+    for (int k = 0; k < nch; ++k) s += partial[((size_t)b * max_chunks + k) * D + d];
+    out[(size_t)b * D + d] = s;
+}
+
+}  // namespace smin
+
+using namespace smin;
+
+extern "C" int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar)
+{
+    SMIN_REQUIRE(D % 4 == 0);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (D / 4);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, fs, cells, N, D / 4, hbar);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, const float* fs, const int32_t* row_ptr,
+                             int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes)
+{
+    (void)N;
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(D % 4 == 0);
+    int cpc, mc; chunking(L, &cpc, &mc);
+    SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * mc * D);
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dhbar, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
+    SMIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sample_partial_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, partial, row_ptr, L, D, cpc, mc, dfs);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}

@@ -6,15 +6,18 @@
 // A and B are "virtual matrices": small functors that produce float4 elements on the fly, so masks,
 // the boundary pair product f_b[i]*f_b[j] and the broadcast clip gradients never touch HBM.
 // Tiles: 128x128 output per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles),
-// K-step 32, register-staged double-buffered LDS, one barrier per K-step.
+// K-step 32, register-staged double-buffered LDS, one barrier per K-step.  All global loads are
+// unconditional (indices are clamped, out-of-range values are selected away) so that hipcc keeps them
+// in flight together instead of branching and waiting per load.  The accumulator tile goes through LDS
+// once more at the end so that epilogues read/write HBM in whole 512-byte row segments (float4 per lane).
 #pragma once
 #include "common.h"
 
 namespace smin {
 
 // ------------------------------------------------------------------ virtual matrices
-// Protocol:  Row row(int r) const   (r < rows() guaranteed by the caller)
-//            float4 at(const Row&, int c) const   (c % 4 == 0, c < cols guaranteed)
+// Protocol:  Row row(int r) const                   (r in range, guaranteed by the caller)
+//            float4 at(const Row&, int c) const     (c % 4 == 0, c in range; must be branch-free)
 
 struct PlainMat {                       // row-major [rows][ld]
     const float* p; int ld;
@@ -40,42 +43,61 @@ struct PairMeanMat {
         return Row{base + (size_t)c.i * D, base + (size_t)c.j * D, fcmean + (size_t)r * D};
     }
     __device__ __forceinline__ float4 at(const Row& r, int c) const {
-        if (c < D) return f4mul(ldg4(r.bi + c), ldg4(r.bj + c));
-        return ldg4(r.cm + (c - D));
+        const bool first = c < D;
+        const float4 a = ldg4(first ? r.bi + c : r.cm + (c - D));
+        const float4 b = ldg4(r.bj + (first ? c : 0));
+        return first ? f4mul(a, b) : a;
     }
 };
 
 // Effective gradient of the content-unit output, row = n*C + c:
-//   dout[n,c,:] = m[n] * ( dfc_out[n,c,:] (may be absent) + dfcmean[n,:] / C )      (MASK: apply m)
-template <bool MASK>
+//   dout[n,c,:] = m[n] * ( dfc_out[n,c,:] (HAS_DFC) + dfcmean[n,:] / C )      (MASK: apply m)
+template <bool MASK, bool HAS_DFC>
 struct DoutEffMat {
     const float* dfc; const float* dmean; const int* cells; int C, D; float invC;
     struct Row { const float* a; const float* b; float m; };
     __device__ __forceinline__ Row row(int r) const {
         const int n = r / C;
-        return Row{dfc ? dfc + (size_t)r * D : nullptr, dmean + (size_t)n * D, MASK ? (float)cells[4 * (size_t)n + 3] : 1.0f};
+        return Row{HAS_DFC ? dfc + (size_t)r * D : nullptr, dmean + (size_t)n * D, MASK ? (float)cells[4 * (size_t)n + 3] : 1.0f};
     }
     __device__ __forceinline__ float4 at(const Row& r, int c) const {
         float4 v = f4scale(ldg4(r.b + c), invC);
-        if (r.a) v = f4add(v, ldg4(r.a + c));
+        if (HAS_DFC) v = f4add(v, ldg4(r.a + c));
         return MASK ? f4scale(v, r.m) : v;
     }
 };
 
-// ------------------------------------------------------------------ MFMA helper
+// ------------------------------------------------------------------ helpers
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ float4 f4sel(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+constexpr int GEMM_LDC = 132;           // row stride (floats) of the staged 128x128 accumulator tile
+
+// Visit the staged tile row-major, one float4 per lane: 32 lanes cover one 512-byte row segment.
+template <class F>
+__device__ __forceinline__ void tile_rows_f4(const float* Cs, int row_base, int col_base, int M, int N, int t, F f)
+{
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int idx = t + 256 * it, r = idx >> 5, c4 = (idx & 31) * 4;
+        const int row = row_base + r, col = col_base + c4;
+        if (row < M && col < N) f(row, col, ldg4(Cs + r * GEMM_LDC + c4));
+    }
+}
 
 // ------------------------------------------------------------------ NT kernel
-// Epilogue protocol: void operator()(int row0, int col, const float v[4]) const
-//   v[q] is C[row0+q][col]; the functor bounds-checks rows/cols itself.
+// Epilogue protocol: void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const
+//   Cs is the 128 x 128 accumulator tile in LDS (row stride GEMM_LDC); t = threadIdx.x.
 template <class AM, class BM_, class EP>
 __global__ __launch_bounds__(256, 2)
 void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int tiles_n)
 {
     constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];      // 73,728 B >= 128 * GEMM_LDC * 4
     float* As = smem;
     float* Bs = smem + 2 * BM * LDT;
 
@@ -88,15 +110,13 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int 
     const int t = threadIdx.x, lr = t >> 3, kq = (t & 7) * 4;
     const int row_base = tm * BM, col_base = tn * BN;
 
+    // out-of-range rows are clamped: they only feed accumulator rows/columns that are never stored
     typename AM::Row arow[4];
     typename BM_::Row brow[4];
-    bool aok[4], bok[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int ra = row_base + lr + 32 * p, rb = col_base + lr + 32 * p;
-        aok[p] = ra < M; bok[p] = rb < N;
-        arow[p] = am.row(aok[p] ? ra : 0);
-        brow[p] = bm.row(bok[p] ? rb : 0);
+        arow[p] = am.row(min(row_base + lr + 32 * p, M - 1));
+        brow[p] = bm.row(min(col_base + lr + 32 * p, N - 1));
     }
 
     const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -112,10 +132,11 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int 
     auto g_load = [&](int k0) {
         const int k = k0 + kq;
         const bool kok = k < K;
+        const int kc = min(k, K - 4);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            ra4[p] = (aok[p] && kok) ? am.at(arow[p], k) : f4zero();
-            rb4[p] = (bok[p] && kok) ? bm.at(brow[p], k) : f4zero();
+            ra4[p] = f4sel(kok, am.at(arow[p], kc));
+            rb4[p] = f4sel(kok, bm.at(brow[p], kc));
         }
     };
     auto s_store = [&](int buf) {
@@ -154,18 +175,19 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int 
         __syncthreads();
     }
 
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // stage the accumulators: C/D layout of a 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* Cs = smem;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row0 = row_base + wm * 64 + mi * 32 + 8 * g + 4 * h;
-                const int col = col_base + wn * 64 + ni * 32 + l31;
-                const float v[4] = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                ep(row0, col, v);
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Cs[row * GEMM_LDC + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
             }
+    __syncthreads();
+    ep.tile(Cs, row_base, col_base, M, N, t);
 }
 
 template <class AM, class BM_, class EP>
@@ -195,8 +217,8 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
     const int m_begin = z * rows_per_split;
     const int m_end = min(Mrows, m_begin + rows_per_split);
     const int t = threadIdx.x, lk = t >> 5, c4 = (t & 31) * 4;
-    const int ia = ti * BI + c4, jb = tj * BJ + c4;
-    const bool iok = ia < I, jok = jb < J;
+    // columns past I / J are clamped: they only feed accumulator entries that are never stored
+    const int ia = min(ti * BI + c4, I - 4), jb = min(tj * BJ + c4, J - 4);
 
     const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     f32x16 acc[2][2];
@@ -213,10 +235,10 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int m = m0 + lk + 8 * p;
-            if (m < m_end) {
-                ra4[p] = iok ? am.at(am.row(m), ia) : f4zero();
-                rb4[p] = jok ? bm.at(bm.row(m), jb) : f4zero();
-            } else { ra4[p] = f4zero(); rb4[p] = f4zero(); }
+            const bool ok = m < m_end;
+            const int mc = min(m, Mrows - 1);
+            ra4[p] = f4sel(ok, am.at(am.row(mc), ia));
+            rb4[p] = f4sel(ok, bm.at(bm.row(mc), jb));
         }
     };
     auto s_store = [&](int buf) {

@@ -8,26 +8,22 @@
 namespace smin {
 
 struct EpMomentOut {                // mu = (acc + bcat) * m + fm
-    const float* bcat; const int* cells; const float* fm; float* out; int M, N;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
-        const float b = bcat[col];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + q;
-            if (row < M) out[(size_t)row * N + col] = (v[q] + b) * (float)cells[4 * (size_t)row + 3] + fm[(size_t)row * N + col];
-        }
+    const float* bcat; const int* cells; const float* fm; float* out;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+            const float m = (float)cells[4 * (size_t)row + 3];
+            stg4(out + (size_t)row * N + col, f4add(f4scale(f4add(v, ldg4(bcat + col)), m), ldg4(fm + (size_t)row * N + col)));
+        });
     }
 };
 
 struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean
-    float* dx1; float* dmean; int M, D;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= 2 * D) return;
-        float* dst = col < D ? dx1 + col : dmean + (col - D);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (row0 + q < M) dst[(size_t)(row0 + q) * D] = v[q];
+    float* dx1; float* dmean; int D;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+            float* dst = col < D ? dx1 + col : dmean + (col - D);
+            stg4(dst + (size_t)row * D, v);
+        });
     }
 };
 
@@ -66,7 +62,7 @@ extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const flo
     (void)B;
     SMIN_REQUIRE(D % 4 == 0);
     return launch_gemm_nt((hipStream_t)stream, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D},
-                          EpMomentOut{bcat, cells, fm, mu, N, D}, N, D, 2 * D);
+                          EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
 }
 
 extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
@@ -83,7 +79,7 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
     SMIN_REQUIRE((size_t)((bslab + (size_t)sp * D) - w) * sizeof(float) <= ws_bytes);
     if (N > 0) {
         // dX = (m * dmu) @ Wcat        [N, 2D], contraction over D
-        int rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, N, D}, N, 2 * D, D);
+        int rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
         if (rc) return rc;
         // dWcat[D, 2D] = (m * dmu)^T @ X ; dbcat = colsum(m * dmu)
         rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
@@ -91,8 +87,8 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
         rc = launch_reduce_slabs(st, slab, dWcat, D * 2 * D, sp); if (rc) return rc;
         rc = launch_reduce_slabs(st, bslab, dbcat, D, sp); if (rc) return rc;
     } else {
-        hipMemsetAsync(dWcat, 0, sizeof(float) * (size_t)D * 2 * D, st);
-        hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
+        (void)hipMemsetAsync(dWcat, 0, sizeof(float) * (size_t)D * 2 * D, st);
+        (void)hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
     }
     hipLaunchKernelGGL(moment_dfb_kernel, dim3(L, B), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, L, D, dfb);
     SMIN_LAUNCH_CHECK();

@@ -158,8 +158,8 @@ extern "C" int smin_score_map_bwd(void* stream, const float* dpm, const float* d
         int rc = launch_reduce_slabs(st, part, dwm, D, nch); if (rc) return rc;
         rc = launch_reduce_slabs(st, bpart, dbm, 1, nch); if (rc) return rc;
     } else {
-        hipMemsetAsync(dwm, 0, sizeof(float) * D, st);
-        hipMemsetAsync(dbm, 0, sizeof(float), st);
+        (void)hipMemsetAsync(dwm, 0, sizeof(float) * D, st);
+        (void)hipMemsetAsync(dbm, 0, sizeof(float), st);
     }
     hipLaunchKernelGGL(score_heads_bwd_kernel, dim3(hch), dim3(128), 0, st, dpsea, psea, fb, BL, D, wb, lmask, dfb, hpart, hbpart);
     SMIN_LAUNCH_CHECK();

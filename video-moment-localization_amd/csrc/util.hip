@@ -42,12 +42,9 @@ __global__ void unpack_cells_kernel(const float* __restrict__ packed, const int*
 }
 
 struct EpStore {
-    float* out; int M, N;
-    __device__ __forceinline__ void operator()(int row0, int col, const float v[4]) const {
-        if (col >= N) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (row0 + q < M) out[(size_t)(row0 + q) * N + col] = v[q];
+    float* out;
+    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
     }
 };
 
@@ -95,6 +92,6 @@ extern "C" int smin_unpack_cells(void* stream, const float* packed, const int32_
 
 extern "C" int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K)
 {
-    SMIN_REQUIRE(K % 4 == 0);
-    return launch_gemm_nt((hipStream_t)stream, PlainMat{A, K}, PlainMat{Bm, K}, EpStore{Cm, M, N}, M, N, K);
+    SMIN_REQUIRE(K % 4 == 0 && N % 4 == 0);
+    return launch_gemm_nt((hipStream_t)stream, PlainMat{A, K}, PlainMat{Bm, K}, EpStore{Cm}, M, N, K);
 }

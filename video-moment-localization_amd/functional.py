@@ -10,6 +10,21 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 
+# bench.py sets RECORD_EVENTS to bracket chosen launches with HIP events on the launch stream
+RECORD_EVENTS = False
+KERNEL_EVENTS = []
+
+
+def _timed_call(tag, name, *args):
+    if not RECORD_EVENTS:
+        return call(name, *args)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    call(name, *args)
+    e.record()
+    KERNEL_EVENTS.append((tag, s, e))
+
+
 def _c(t):
     return None if t is None else t.contiguous()
 
@@ -54,81 +69,106 @@ class ProposalMapFn(Function):
         return df, None, None, None, None
 
 
+class GateFn(Function):
+    """hbar = sigmoid(fm * fs) * fm -- the gated moment feature of models.py:191 and 272-274, computed once
+    per layer and shared by the content and boundary units."""
+
+    @staticmethod
+    def forward(ctx, fm, fs, layout):
+        fm, fs = _c(fm), _c(fs)
+        N, D = fm.shape
+        hbar = torch.empty_like(fm)
+        call("smin_gate_fwd", stream(), ptr(fm), ptr(fs), ptr(layout.cells), N, D, ptr(hbar))
+        ctx.save_for_backward(fm, fs)
+        ctx.layout = layout
+        return hbar
+
+    @staticmethod
+    def backward(ctx, dhbar):
+        fm, fs = ctx.saved_tensors
+        layout = ctx.layout
+        N, D = fm.shape
+        dhbar = _c(dhbar)
+        dfm, dfs = torch.empty_like(fm), torch.empty_like(fs)
+        _, wp, wn = _ws(4 * layout.B * 64 * D + 4096, fm.device)
+        call("smin_gate_bwd", stream(), ptr(dhbar), ptr(fm), ptr(fs), ptr(layout.row_ptr), N, layout.B, layout.L, D,
+             ptr(dfm), ptr(dfs), wp, wn)
+        return dfm, dfs, None
+
+
 class ContentUnitFn(Function):
     """ContentUnit.forward + ContentAttention.forward (reference models.py:207-226, 242-276).
 
-    Inputs: fc [N,C,D], fm [N,D], fs [B,D], linear_c_hat (Wch, bch), the folded word-side operands
+    Inputs: fc [N,C,D], hbar [N,D] (GateFn), linear_c_hat (Wch, bch), the folded word-side operands
     Mq/uq/what/shat (see smin_hip.h), qmask [B,Nq] fp32, linear_c (Wc, bc).
     Outputs: fc_out [N,C,D], fcmean [N,D]."""
 
     @staticmethod
-    def forward(ctx, fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc, layout):
-        fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc = map(_c, (fc, fm, fs, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc))
+    def forward(ctx, fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc, layout):
+        fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc = map(_c, (fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc))
         N, C, D = fc.shape
         B, Nq, dl = what.shape
         fc_out = torch.empty_like(fc)
         fcmean = fc.new_empty((N, D))
         chat = fc.new_empty((N * C, dl))
         cchat = fc.new_empty((N * C, dl))
-        call("smin_content_unit_fwd", stream(), ptr(fc), ptr(fm), ptr(layout.cells), ptr(layout.row_ptr), N, B, layout.L, C, D, dl, Nq,
-             ptr(fs), ptr(Wch), ptr(bch), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(Wc), ptr(bc),
+        call("smin_content_unit_fwd", stream(), ptr(fc), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr), N, B, layout.L, C, D, dl, Nq,
+             ptr(Wch), ptr(bch), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(Wc), ptr(bc),
              ptr(fc_out), ptr(fcmean), ptr(chat), ptr(cchat))
-        ctx.save_for_backward(fc, fm, fs, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat)
+        ctx.save_for_backward(fc, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat)
         ctx.layout = layout
         return fc_out, fcmean
 
     @staticmethod
     def backward(ctx, dfc_out, dfcmean):
-        fc, fm, fs, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat = ctx.saved_tensors
+        fc, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat = ctx.saved_tensors
         layout = ctx.layout
         N, C, D = fc.shape
         B, Nq, dl = what.shape
         dfc_out = _c(dfc_out)
-        dfcmean = _c(dfcmean) if dfcmean is not None else fm.new_zeros((N, D))
+        dfcmean = _c(dfcmean) if dfcmean is not None else fc.new_zeros((N, D))
         WchT, WcT = Wch.t().contiguous(), Wc.t().contiguous()
-        dfc, dfm, dfs = torch.empty_like(fc), torch.empty_like(fm), torch.empty_like(fs)
+        dfc, dhbar = torch.empty_like(fc), fc.new_empty((N, D))
         dWch, dbch = torch.empty_like(Wch), fc.new_empty((dl,))
         dMq, duq, dwhat, dshat = torch.empty_like(Mq), torch.empty_like(uq), torch.empty_like(what), torch.empty_like(shat)
         dWc, dbc = torch.empty_like(Wc), fc.new_empty((D,))
         if N == 0:
-            for t in (dfs, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc):
+            for t in (dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc):
                 t.zero_()
         else:
             _, wp, wn = _unit_ws(layout, C, D, dl, Nq, fc.device)
-            call("smin_content_unit_bwd", stream(), ptr(dfc_out), ptr(dfcmean), ptr(fc), ptr(fm), ptr(layout.cells), ptr(layout.row_ptr),
-                 N, B, layout.L, C, D, dl, Nq, ptr(fs), ptr(Wch), ptr(WchT), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(WcT),
-                 ptr(chat), ptr(cchat), ptr(dfc), ptr(dfm), ptr(dfs), ptr(dWch), ptr(dbch), ptr(dMq), ptr(duq), ptr(dwhat), ptr(dshat),
+            call("smin_content_unit_bwd", stream(), ptr(dfc_out), ptr(dfcmean), ptr(fc), ptr(layout.cells), ptr(layout.row_ptr),
+                 N, B, layout.L, C, D, dl, Nq, ptr(WchT), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(WcT),
+                 ptr(chat), ptr(cchat), ptr(dfc), ptr(dhbar), ptr(dWch), ptr(dbch), ptr(dMq), ptr(duq), ptr(dwhat), ptr(dshat),
                  ptr(dWc), ptr(dbc), wp, wn)
-        return dfc, dfm, dfs, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None
+        return dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None
 
 
 class BoundaryReduceFn(Function):
-    """The map-sized term of BoundaryUnit.forward (reference models.py:190-194)."""
+    """The map-sized term of BoundaryUnit.forward (reference models.py:190-194): fbm = sum_j A_b[i,j] hbar[(i,j)]."""
 
     @staticmethod
-    def forward(ctx, Ab, fm, fs, layout):
-        Ab, fm, fs = _c(Ab), _c(fm), _c(fs)
+    def forward(ctx, Ab, hbar, layout):
+        Ab, hbar = _c(Ab), _c(hbar)
         B, L, _ = Ab.shape
-        D = fm.shape[1]
-        fbm = fm.new_empty((B, L, D))
-        call("smin_boundary_reduce_fwd", stream(), ptr(Ab), ptr(fm), ptr(fs), ptr(layout.cells), ptr(layout.row_ptr),
-             layout.N, B, L, D, ptr(fbm))
-        ctx.save_for_backward(Ab, fm, fs)
+        D = hbar.shape[1]
+        fbm = hbar.new_empty((B, L, D))
+        call("smin_boundary_reduce_fwd", stream(), ptr(Ab), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr), layout.N, B, L, D, ptr(fbm))
+        ctx.save_for_backward(Ab, hbar)
         ctx.layout = layout
         return fbm
 
     @staticmethod
     def backward(ctx, dfbm):
-        Ab, fm, fs = ctx.saved_tensors
+        Ab, hbar = ctx.saved_tensors
         layout = ctx.layout
         B, L, _ = Ab.shape
-        D = fm.shape[1]
+        D = hbar.shape[1]
         dfbm = _c(dfbm)
-        dAb, dfm, dfs = torch.empty_like(Ab), torch.empty_like(fm), torch.empty_like(fs)
-        _, wp, wn = _ws(4 * B * L * D, fm.device)
-        call("smin_boundary_reduce_bwd", stream(), ptr(dfbm), ptr(Ab), ptr(fm), ptr(fs), ptr(layout.cells), ptr(layout.row_ptr),
-             layout.N, B, L, D, ptr(dAb), ptr(dfm), ptr(dfs), wp, wn)
-        return dAb, dfm, dfs, None
+        dAb, dhbar = torch.empty_like(Ab), torch.empty_like(hbar)
+        call("smin_boundary_reduce_bwd", stream(), ptr(dfbm), ptr(Ab), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr),
+             layout.N, B, L, D, ptr(dAb), ptr(dhbar))
+        return dAb, dhbar, None
 
 
 class MomentUnitFn(Function):
@@ -140,7 +180,7 @@ class MomentUnitFn(Function):
         N, D = fm.shape
         B, L, _ = fb.shape
         mu = torch.empty_like(fm)
-        call("smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu))
+        _timed_call("moment_unit_fwd", "smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu))
         ctx.save_for_backward(fcmean, fb, Wcat)
         ctx.layout = layout
         return mu

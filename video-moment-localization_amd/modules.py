@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .cells import CellLayout
-from .functional import BoundaryReduceFn, ContentUnitFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
+from .functional import BoundaryReduceFn, ContentUnitFn, GateFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
 
 
 def _rows(mask):
@@ -142,7 +142,7 @@ class BoundaryUnit(nn.Module):
         self.D = D
         self.attn_layer = Attention(D)
 
-    def forward_packed(self, f_b, f_w, f_s, fm, query_mask, length_mask, layout):
+    def forward_packed(self, f_b, f_w, f_s, hbar, query_mask, length_mask, layout):
         lm = length_mask.float()
         lcol = lm.unsqueeze(-1)
         baq = self.attn_layer(f_b, f_w, f_w, query_mask) * lcol
@@ -151,13 +151,14 @@ class BoundaryUnit(nn.Module):
         lrow = lm.unsqueeze(1)
         A = torch.softmax((z * lrow).masked_fill(lrow == 0, -1e9), dim=-1) * lcol
         f_bb = torch.bmm(A, f_b) * lcol
-        f_bm = BoundaryReduceFn.apply(A, fm, f_s, layout)          # HIP: gated row reduction of the map
+        f_bm = BoundaryReduceFn.apply(A, hbar, layout)             # HIP: gated row reduction of the map
         return f_bb + f_b + f_bm
 
     def forward(self, f_b, f_w, f_s, f_m, query_mask, length_mask):
         B, L = f_m.shape[:2]
         layout = CellLayout.all_cells(torch.ones(B, L, L, dtype=torch.bool, device=f_m.device))
-        return self.forward_packed(f_b, f_w, f_s, layout.pack(f_m), query_mask, length_mask, layout)
+        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)
+        return self.forward_packed(f_b, f_w, f_s, hbar, query_mask, length_mask, layout)
 
 
 class ContentAttention(nn.Module):
@@ -189,7 +190,7 @@ class ContentUnit(nn.Module):
         self.linear_c = nn.Linear(dl, D)
         self.attn_layer = ContentAttention(dl)
 
-    def forward_packed(self, fc, fm, f_w, f_s, query_mask, layout):
+    def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout):
         qm = _rows(query_mask)
         what = self.linear_w_hat(f_w) * qm.unsqueeze(-1)
         shat = self.linear_s_hat(f_s)
@@ -197,12 +198,13 @@ class ContentUnit(nn.Module):
         # W_q(c_hat) . kb^T == c_hat . (kb W_q.weight)^T + kb . W_q.bias : the per-cell dl x dl projection folds away
         Mq = torch.matmul(kb, self.attn_layer.W_q.weight)
         uq = torch.matmul(kb, self.attn_layer.W_q.bias)
-        return ContentUnitFn.apply(fc, fm, f_s, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
+        return ContentUnitFn.apply(fc, hbar, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
                                    self.linear_c.weight, self.linear_c.bias, layout)
 
     def forward(self, f_c, f_w, f_s, f_m, query_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
-        out, _ = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_w, f_s, query_mask, layout)
+        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)
+        out, _ = self.forward_packed(layout.pack(f_c), hbar, f_w, f_s, query_mask, layout)
         return layout.unpack(out)
 
 
@@ -238,8 +240,9 @@ class SMI(nn.Module):
         self.moment_unit = MomentUnit(D)
 
     def forward_packed(self, fc, fm, f_b, f_w, f_s, query_mask, length_mask, layout):
-        cu, cumean = self.content_unit.forward_packed(fc, fm, f_w, f_s, query_mask, layout)
-        bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, fm, query_mask, length_mask, layout)
+        hbar = GateFn.apply(fm, f_s, layout)                      # sigmoid(fm*fs)*fm, shared by both units
+        cu, cumean = self.content_unit.forward_packed(fc, hbar, f_w, f_s, query_mask, layout)
+        bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, hbar, query_mask, length_mask, layout)
         mu = self.moment_unit.forward_packed(cumean, fm, bu, layout)
         return cu, mu, bu
 
