@@ -1,0 +1,544 @@
+// ContentAttention core on the matrix cores (reference models.py:207-226 and 253-266), fp32 MFMA 32x32x2.
+//
+// One wave owns a tile of 8 cells = 32 "rows" (row j = 4*cell + clip; clips >= C are zero padding).  Rows live on
+// the MFMA column index (lane & 31), so every per-row vector (chat, a, q, gradients) is held by the lane pair
+// (j, j+32) as 2 x 64 registers in exactly the accumulator layout  d = 8*kg + 4*(lane>>5) + q :
+//   S^T[w][j]  = sum_d Mq[w][d] chat[j][d]          MFMA  A = Mq (LDS, rows = words), B = chat (registers)
+//   P          = softmax over words                  in-register: 16 values per lane + one cross-half exchange
+//   a^T[d][j]  = sum_w what[w][d] P^T[w][j]         MFMA  A = what^T (LDS), B = the P accumulator as is
+//   q, Z = q q^T over the 4 clips of a cell, A = softmax(Z), cchat = A chat        VALU + DPP quad permutes
+// The backward pass mirrors it (dP^T = what . da^T and dchat^T += Mq^T . dS^T on MFMA) and streams da, dS and P
+// to HBM; the per-sample word-side reductions (dMq, dwhat, dshat, duq) are a second, MFMA "TN" kernel that reads
+// them back coalesced -- fixed-order partial slabs keep everything deterministic.
+#include "content_attn.h"
+
+namespace smin {
+
+constexpr int LDW = 36;                                       // row stride of the transposed [d][w] LDS images
+
+template <int CTRL>
+__device__ __forceinline__ float qperm(float v) {             // quad permute (DPP): neighbour lane j ^ o
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int O> __device__ __forceinline__ float nb(float v);
+template <> __device__ __forceinline__ float nb<0>(float v) { return v; }
+template <> __device__ __forceinline__ float nb<1>(float v) { return qperm<0xB1>(v); }    // [1,0,3,2]
+template <> __device__ __forceinline__ float nb<2>(float v) { return qperm<0x4E>(v); }    // [2,3,0,1]
+template <> __device__ __forceinline__ float nb<3>(float v) { return qperm<0x1B>(v); }    // [3,2,1,0]
+
+// acc_o += nb<o>(x) * y_o for o = 1, 2, 3 as three fused DPP FMAs.  Written as one asm statement because hipcc
+// otherwise materialises all neighbour values of a whole tile first (hundreds of live VGPRs, scratch spills).
+// The leading s_nop 1 covers the "VALU write -> DPP read" hazard for x (asm is not padded by the compiler).
+__device__ __forceinline__ void fmac_nb3(float& a1, float& a2, float& a3, float x, float y1, float y2, float y3) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %1, %3, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %2, %3, %6 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y1), "v"(y2), "v"(y3));
+}
+// acc += sum_{o=1..3} nb<o>(x) * y_o
+__device__ __forceinline__ void fmac_nb_sum(float& acc, float x, float y1, float y2, float y3) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %0, %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %0, %1, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(acc) : "v"(x), "v"(y1), "v"(y2), "v"(y3));
+}
+
+__device__ __forceinline__ int wmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// LDS carve (floats).  sM/sW: [32][DL+4] word-major; sMT/sWT: [DLP][36] feature-major (DLP = DL rounded to 32).
+template <int DL>
+struct AttnLds {
+    static constexpr int LDM = DL + 4;
+    static constexpr int DLP = (DL + 31) / 32 * 32;
+    float *sM, *sW, *sMT, *sWT, *sS, *sU, *sQ;
+    __device__ AttnLds(float* base, bool bwd) {
+        sM = base; sWT = sM + 32 * LDM; sS = sWT + DLP * LDW; sU = sS + DL; sQ = sU + 32;
+        sW = sQ + 32; sMT = sW + (bwd ? 32 * LDM : 0);
+    }
+    static size_t bytes(bool bwd) { return sizeof(float) * (size_t)(32 * LDM + DLP * LDW + DL + 64 + (bwd ? 32 * LDM + DLP * LDW : 0)); }
+};
+
+template <int DL>
+__device__ __forceinline__ void stage_sample(const AttnLds<DL>& s, bool bwd, const float* Mq, const float* uq, const float* what,
+                                             const float* shat, const float* qmask, int b, int dl, int Nq)
+{
+    constexpr int LDM = AttnLds<DL>::LDM, DLP = AttnLds<DL>::DLP;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < 32 * LDM; idx += 256) {
+        const int w = idx / LDM, d = idx % LDM;
+        const bool ok = w < Nq && d < dl;
+        s.sM[idx] = ok ? Mq[((size_t)b * Nq + w) * dl + d] : 0.f;
+        if (bwd) s.sW[idx] = ok ? what[((size_t)b * Nq + w) * dl + d] : 0.f;
+    }
+    for (int idx = t; idx < DLP * LDW; idx += 256) {
+        const int d = idx / LDW, w = idx % LDW;
+        const bool ok = w < Nq && d < dl;
+        s.sWT[idx] = ok ? what[((size_t)b * Nq + w) * dl + d] : 0.f;
+        if (bwd) s.sMT[idx] = ok ? Mq[((size_t)b * Nq + w) * dl + d] : 0.f;
+    }
+    for (int d = t; d < DL; d += 256) s.sS[d] = d < dl ? shat[(size_t)b * dl + d] : 0.f;
+    if (t < 32) {
+        s.sU[t] = t < Nq ? uq[(size_t)b * Nq + t] : 0.f;
+        s.sQ[t] = t < Nq ? qmask[(size_t)b * Nq + t] : 0.f;
+    }
+}
+
+// per-lane geometry of a tile
+struct RowGeom {
+    int row;            // global row index n*C + c (clamped to a valid row when !ok)
+    bool ok;            // this lane carries a real (cell, clip)
+    float m;            // cell mask
+    bool nbok[4];       // neighbour clip c ^ o exists
+};
+__device__ __forceinline__ RowGeom row_geom(const int* cells, int n0, int n_end, int C, int lane) {
+    const int j = lane & 31, cell = n0 + (j >> 2), c = j & 3;
+    RowGeom g;
+    g.ok = cell < n_end && c < C;
+    const int cc = g.ok ? cell : n0;
+    g.row = cc * C + (g.ok ? c : 0);
+    g.m = g.ok ? (float)cells[4 * (size_t)cc + 3] : 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) g.nbok[o] = (c ^ o) < C;
+    return g;
+}
+
+// ---- forward pieces --------------------------------------------------------------------------------------------
+template <int DL>
+__device__ __forceinline__ void load_rows(float (&v)[DL / 8][4], const float* src, const RowGeom& g, int dl, int h) {
+#pragma unroll
+    for (int kg = 0; kg < DL / 8; ++kg) {
+        const int d = 8 * kg + 4 * h;
+        const float4 x = ldg4(src + (size_t)g.row * dl + min(d, dl - 4));
+        const bool ok = g.ok && d < dl;
+        v[kg][0] = ok ? x.x : 0.f; v[kg][1] = ok ? x.y : 0.f; v[kg][2] = ok ? x.z : 0.f; v[kg][3] = ok ? x.w : 0.f;
+    }
+}
+template <int DL>
+__device__ __forceinline__ void store_rows(float* dst, const float (&v)[DL / 8][4], const RowGeom& g, int dl, int h, float scale) {
+#pragma unroll
+    for (int kg = 0; kg < DL / 8; ++kg) {
+        const int d = 8 * kg + 4 * h;
+        if (g.ok && d < dl) stg4(dst + (size_t)g.row * dl + d, make_float4(v[kg][0] * scale, v[kg][1] * scale, v[kg][2] * scale, v[kg][3] * scale));
+    }
+}
+
+// P^T[w][j] (16 words per lane) from chat
+template <int DL>
+__device__ __forceinline__ void scores_softmax(float (&P)[16], const float (&ch)[DL / 8][4], const AttnLds<DL>& s, int Nq, float scale, int lane)
+{
+    constexpr int LDM = AttnLds<DL>::LDM;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < DL / 8; ++kg) {
+        const float4 a4 = ldg4(s.sM + l31 * LDM + 8 * kg + 4 * h);
+        S = mfma32(a4.x, ch[kg][0], S); S = mfma32(a4.y, ch[kg][1], S);
+        S = mfma32(a4.z, ch[kg][2], S); S = mfma32(a4.w, ch[kg][3], S);
+        if ((kg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int w = wmap(r, h);
+        float v = (S[r] + s.sU[w]) * scale;
+        const float qm = s.sQ[w];
+        v = (qm == 0.f) ? -1e9f : v * qm;                         // models.py:216-218
+        v = (w < Nq) ? v : -INFINITY;
+        P[r] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { P[r] = expf(P[r] - mx); den += P[r]; }
+    den += __shfl_xor(den, 32);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[r] *= inv;
+}
+
+// one 32-feature tile of a^T[d][j] = sum_w what[w][d] P^T[w][j]   (accumulator layout: d = 32*dt + 8*(r>>2) + 4h + (r&3))
+template <int DL>
+__device__ __forceinline__ f32x16 attend_tile(int dt, const float (&P)[16], const AttnLds<DL>& s, int Nq, int lane)
+{
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (8 * g < Nq) {
+            const float4 w4 = ldg4(s.sWT + (32 * dt + l31) * LDW + 8 * g + 4 * h);
+            acc = mfma32(w4.x, P[4 * g], acc); acc = mfma32(w4.y, P[4 * g + 1], acc);
+            acc = mfma32(w4.z, P[4 * g + 2], acc); acc = mfma32(w4.w, P[4 * g + 3], acc);
+        }
+    }
+    return acc;
+}
+
+// clip self-attention weights of this lane's row: Ao[o] = softmax_c'(q_c . q_c' / sqrt(dl))[c ^ o] * m,
+// q = chat * (a + shat); a is produced tile by tile on the matrix core and never held whole.
+template <int DL>
+__device__ __forceinline__ void clip_attention(float (&Ao)[4], const float (&ch)[DL / 8][4], const float (&P)[16],
+                                               const AttnLds<DL>& s, const RowGeom& g, int Nq, float scale, int lane)
+{
+    const int h = lane >> 5;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
+        const f32x16 acc = attend_tile<DL>(dt, P, s, Nq, lane);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            if (4 * dt + gq < DL / 8) {
+                const float4 sh = ldg4(s.sS + 8 * (4 * dt + gq) + 4 * h);
+                const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float qv = ch[(4 * dt + gq) % (DL / 8)][q] * (acc[4 * gq + q] + shv[q]);
+                    z[0] = fmaf(qv, qv, z[0]);
+                    fmac_nb3(z[1], z[2], z[3], qv, qv, qv, qv);
+                }
+            }
+            if (gq == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        z[o] = (z[o] + __shfl_xor(z[o], 32)) * scale;
+        z[o] = g.nbok[o] ? z[o] : -INFINITY;
+        mx = fmaxf(mx, z[o]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { Ao[o] = expf(z[o] - mx); den += Ao[o]; }
+    const float inv = g.m / den;                                  // models.py:262-263: softmax, then * mask
+#pragma unroll
+    for (int o = 0; o < 4; ++o) Ao[o] *= inv;
+}
+
+template <int DL>
+__global__ __launch_bounds__(256, 2)
+void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
+                                  const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
+                                  const float* __restrict__ shat, const float* __restrict__ qmask,
+                                  float* __restrict__ cchat, int dl, int Nq, int cells_per_chunk, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
+    const int n_begin = s0 + chunk * cells_per_chunk;
+    if (n_begin >= s1) return;
+    const int n_end = min(s1, n_begin + cells_per_chunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    AttnLds<DL> s(smem_dyn, false);
+    stage_sample<DL>(s, false, Mq, uq, what, shat, qmask, b, dl, Nq);
+    __syncthreads();
+
+    for (int n0 = n_begin + 8 * wave; n0 < n_end; n0 += 32) {
+        const RowGeom g = row_geom(cells, n0, n_end, C, lane);
+        float ch[DL / 8][4], P[16], Ao[4];
+        load_rows<DL>(ch, chat, g, dl, h);
+        scores_softmax<DL>(P, ch, s, Nq, scale, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        clip_attention<DL>(Ao, ch, P, s, g, Nq, scale, lane);
+#pragma unroll
+        for (int kg = 0; kg < DL / 8; ++kg) {                       // cchat = A chat
+            float o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = ch[kg][q];
+                o4[q] = Ao[0] * x;
+                fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
+            }
+            const int d = 8 * kg + 4 * h;
+            if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+            if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+template <int DL>
+__global__ __launch_bounds__(256, 2)
+void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
+                                  const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
+                                  const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
+                                  const float* __restrict__ shat, const float* __restrict__ qmask,
+                                  float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
+                                  int dl, int Nq, int cells_per_chunk, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    constexpr int LDM = AttnLds<DL>::LDM, KG = DL / 8;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
+    const int n_begin = s0 + chunk * cells_per_chunk;
+    if (n_begin >= s1) return;
+    const int n_end = min(s1, n_begin + cells_per_chunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    AttnLds<DL> s(smem_dyn, true);
+    stage_sample<DL>(s, true, Mq, uq, what, shat, qmask, b, dl, Nq);
+    __syncthreads();
+
+    for (int n0 = n_begin + 8 * wave; n0 < n_end; n0 += 32) {
+        const RowGeom g = row_geom(cells, n0, n_end, C, lane);
+        float ch[KG][4], P[16], Ao[4];
+        load_rows<DL>(ch, chat, g, dl, h);
+        scores_softmax<DL>(P, ch, s, Nq, scale, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        clip_attention<DL>(Ao, ch, P, s, g, Nq, scale, lane);
+
+        // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}   (g streamed, never held whole)
+        float dch[KG][4];
+        float dAo[4] = {0.f, 0.f, 0.f, 0.f};
+        const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int d = 8 * kg + 4 * h;
+            const float4 g4 = ldg4(dcchat + (size_t)g.row * dl + min(d, dl - 4));
+            const bool ok = g.ok && d < dl;
+            const float gv[4] = {ok ? g4.x : 0.f, ok ? g4.y : 0.f, ok ? g4.z : 0.f, ok ? g4.w : 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = ch[kg][q], y = gv[q];
+                dAo[0] = fmaf(y, x, dAo[0]);
+                fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
+                dch[kg][q] = Ao[0] * y;
+                fmac_nb_sum(dch[kg][q], y, An1, An2, An3);
+            }
+            if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // A = softmax(Z) * m ; Z symmetric in (c, c')
+        float sym[4];
+        {
+            float rd = 0.f, dZ[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { dAo[o] = (dAo[o] + __shfl_xor(dAo[o], 32)); rd = fmaf(Ao[o], dAo[o], rd); }
+            // Ao already carries m; with m == 0 everything below vanishes, with m == 1 this is the softmax Jacobian
+#pragma unroll
+            for (int o = 0; o < 4; ++o) dZ[o] = g.nbok[o] ? Ao[o] * (dAo[o] - rd) : 0.f;
+            sym[0] = 2.0f * dZ[0] * scale;
+            sym[1] = (dZ[1] + nb<1>(dZ[1])) * scale;
+            sym[2] = (dZ[2] + nb<2>(dZ[2])) * scale;
+            sym[3] = (dZ[3] + nb<3>(dZ[3])) * scale;
+        }
+        // per 32-feature tile: a (MFMA) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
+        //                      -> da to HBM and straight into  dP^T[w][j] += sum_d what[w][d] da^T[d][j]  (MFMA)
+        f32x16 dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dP[r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
+            const f32x16 acc = attend_tile<DL>(dt, P, s, Nq, lane);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (4 * dt + gq < KG) {
+                    constexpr int KGm = KG;
+                    const int kg = (4 * dt + gq) % KGm;
+                    const float4 sh = ldg4(s.sS + 8 * kg + 4 * h);
+                    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    float da4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float tq = acc[4 * gq + q] + shv[q];
+                        const float qv = ch[kg][q] * tq;
+                        float dq = sym[0] * qv;
+                        fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
+                        dch[kg][q] = fmaf(dq, tq, dch[kg][q]);
+                        da4[q] = dq * ch[kg][q];
+                    }
+                    const int d = 8 * kg + 4 * h;
+                    if (g.ok && d < dl) stg4(da_out + (size_t)g.row * dl + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
+                    const float4 w4 = ldg4(s.sW + l31 * LDM + 8 * kg + 4 * h);
+                    dP = mfma32(w4.x, da4[0], dP); dP = mfma32(w4.y, da4[1], dP);
+                    dP = mfma32(w4.z, da4[2], dP); dP = mfma32(w4.w, da4[3], dP);
+                }
+                if (gq == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // P = softmax(S), S = (raw + u) * scale * qmask
+        float pd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pd = fmaf(P[r], dP[r], pd);
+        pd += __shfl_xor(pd, 32);
+        float dS[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dS[r] = P[r] * (dP[r] - pd) * s.sQ[wmap(r, h)] * scale;
+        if (g.ok) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                stg4(ds_out + (size_t)g.row * 32 + 8 * gq + 4 * h, make_float4(dS[4 * gq], dS[4 * gq + 1], dS[4 * gq + 2], dS[4 * gq + 3]));
+                stg4(p_out + (size_t)g.row * 32 + 8 * gq + 4 * h, make_float4(P[4 * gq], P[4 * gq + 1], P[4 * gq + 2], P[4 * gq + 3]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // raw = chat Mq^T :  dchat^T[d][j] += sum_w Mq[w][d] dS^T[w][j]   -> dchat = (...) * m   (chat = linear(fc) * m)
+#pragma unroll
+        for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (4 * dt + (r >> 2) < KG) ? dch[(4 * dt + (r >> 2)) % KG][r & 3] : 0.f;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (8 * gq < Nq) {
+                    const float4 m4 = ldg4(s.sMT + (32 * dt + l31) * LDW + 8 * gq + 4 * h);
+                    acc = mfma32(m4.x, dS[4 * gq], acc); acc = mfma32(m4.y, dS[4 * gq + 1], acc);
+                    acc = mfma32(m4.z, dS[4 * gq + 2], acc); acc = mfma32(m4.w, dS[4 * gq + 3], acc);
+                }
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (4 * dt + gq < KG) {
+                    const int d = 8 * (4 * dt + gq) + 4 * h;
+                    if (g.ok && d < dl)
+                        stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[4 * gq] * g.m, acc[4 * gq + 1] * g.m, acc[4 * gq + 2] * g.m, acc[4 * gq + 3] * g.m));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- per-sample word-side reductions on MFMA (operands straight from HBM, coalesced) ---------------------------
+//   dMq[w][d]  = sum_rows dS[row][w] chat[row][d]      dwhat[w][d] = sum_rows P[row][w] da[row][d]
+//   dshat[d]   = sum_rows da[row][d]                   duq[w]      = sum_rows dS[row][w]
+// grid (SPLITS, B); each wave reduces a contiguous row range and writes one partial slab
+//   [dM 32 x dl | dW 32 x dl | dshat dl | du 32]; content_attn_reduce_kernel sums the slabs in fixed order.
+template <int DL>
+__global__ __launch_bounds__(256, 2)
+void content_attn_wordgrad_kernel(const float* __restrict__ chat, const float* __restrict__ da, const float* __restrict__ dS, const float* __restrict__ P,
+                                  const int* __restrict__ row_ptr, int L, int C, int dl, int splits, float* __restrict__ slab)
+{
+    constexpr int DT = (DL + 31) / 32;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    const int r0 = row_ptr[b * L] * C, r1 = row_ptr[(b + 1) * L] * C;
+    const int parts = splits * 4, part = sp * 4 + wave;
+    const int per = ((r1 - r0 + parts - 1) / parts + 1) & ~1;            // even number of rows per wave
+    const int rb = r0 + part * per, re = min(r1, rb + per);
+    f32x16 aM[DT], aW[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aM[dt][r] = 0.f; aW[dt][r] = 0.f; }
+    float sh[DT], du = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) sh[dt] = 0.f;
+    for (int row2 = rb; row2 < re; row2 += 2) {                  // wave-uniform trip count: MFMA needs every lane live
+        const bool ok = row2 + h < re;
+        const size_t row = (size_t)min(row2 + h, re - 1);
+        const float gs = ok ? dS[row * 32 + l31] : 0.f, ps = ok ? P[row * 32 + l31] : 0.f;
+        du += gs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = min(32 * dt + l31, dl - 1);
+            const bool dok = ok && 32 * dt + l31 < dl;
+            const float cv = dok ? chat[row * dl + d] : 0.f;
+            const float dv = dok ? da[row * dl + d] : 0.f;
+            sh[dt] += dv;
+            aM[dt] = mfma32(gs, cv, aM[dt]);
+            aW[dt] = mfma32(ps, dv, aW[dt]);
+        }
+    }
+    const size_t slab_sz = (size_t)2 * 32 * dl + dl + 32;
+    float* sl = slab + ((size_t)b * parts + part) * slab_sz;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = wmap(r, h), d = 32 * dt + l31;
+            if (d < dl) { sl[(size_t)w * dl + d] = aM[dt][r]; sl[(size_t)(32 + w) * dl + d] = aW[dt][r]; }
+        }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const float v = sh[dt] + __shfl_xor(sh[dt], 32);
+        const int d = 32 * dt + l31;
+        if (h == 0 && d < dl) sl[(size_t)64 * dl + d] = v;
+    }
+    du += __shfl_xor(du, 32);
+    if (h == 0) sl[(size_t)64 * dl + dl + l31] = du;
+}
+
+__global__ void content_attn_reduce_kernel(const float* __restrict__ slab, int dl, int Nq, int parts,
+                                           float* __restrict__ dMq, float* __restrict__ dwhat, float* __restrict__ dshat, float* __restrict__ duq)
+{
+    const int b = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slab_sz = 2 * 32 * dl + dl + 32;
+    if (x >= slab_sz) return;
+    const float* p = slab + (size_t)b * parts * slab_sz + x;
+    float s = 0.f;
+    for (int k = 0; k < parts; ++k) s += p[(size_t)k * slab_sz];
+    if (x < 32 * dl) { const int w = x / dl, d = x % dl; if (w < Nq) dMq[((size_t)b * Nq + w) * dl + d] = s; }
+    else if (x < 64 * dl) { const int y = x - 32 * dl, w = y / dl, d = y % dl; if (w < Nq) dwhat[((size_t)b * Nq + w) * dl + d] = s; }
+    else if (x < 64 * dl + dl) dshat[(size_t)b * dl + (x - 64 * dl)] = s;
+    else { const int w = x - 64 * dl - dl; if (w < Nq) duq[(size_t)b * Nq + w] = s; }
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------
+template <int DL>
+static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
+                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask, float* cchat, int dl, int Nq)
+{
+    int cpc, mc; chunking(L, &cpc, &mc);
+    hipLaunchKernelGGL((content_attn_fwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(false), st, chat, cells, row_ptr, L, C,
+                       Mq, uq, what, shat, qmask, cchat, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
+                            const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                            float* cchat, int dl, int Nq)
+{
+    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+}
+
+size_t content_attn_bwd_ws_floats(int M, int B, int dl)
+{
+    return (size_t)M * dl + 2 * (size_t)M * 32 + (size_t)B * ATTN_SPLITS * 4 * ((size_t)64 * dl + dl + 32) + 64;
+}
+
+template <int DL>
+static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
+                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq)
+{
+    int cpc, mc; chunking(L, &cpc, &mc);
+    float* da = ws;
+    float* dS = da + (size_t)M * dl;
+    float* P = dS + (size_t)M * 32;
+    float* slab = P + (size_t)M * 32;
+    hipLaunchKernelGGL((content_attn_bwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(true), st, chat, dcchat, cells, row_ptr, L, C,
+                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
+    SMIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL((content_attn_wordgrad_kernel<DL>), dim3(ATTN_SPLITS, B), dim3(256), 0, st, chat, da, dS, P, row_ptr, L, C, dl, ATTN_SPLITS, slab);
+    SMIN_LAUNCH_CHECK();
+    const int slab_sz = 64 * dl + dl + 32;
+    hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, slab, dl, Nq, ATTN_SPLITS * 4, dMq, dwhat, dshat, duq);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
+                            const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq)
+{
+    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
+    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
+    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
+    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
+}
+
+}  // namespace smin
