@@ -16,8 +16,8 @@ namespace smin {
 // ------------------------------------------------------------------ epilogues (see gemm.h: tile protocol)
 struct EpBiasMask {                 // chat[row][col] = (acc + bias[col]) * m[row / C]
     const float* bias; const int* cells; float* out; int C;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             const float m = (float)cells[4 * (size_t)(row / C) + 3];
             stg4(out + (size_t)row * N + col, f4scale(f4add(v, ldg4(bias + col)), m));
         });
@@ -27,8 +27,8 @@ struct EpBiasMask {                 // chat[row][col] = (acc + bias[col]) * m[ro
 // out = (acc + bc) * m + fc + hbar[n]      (models.py:269-276; hbar = sigmoid(fm*fs)*fm from gate.hip)
 struct EpContentOut {               // any C
     const float* bc; const int* cells; const float* fc; const float* hbar; float* out; int C;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             const int n = row / C;
             const float m = (float)cells[4 * (size_t)n + 3];
             const float4 o = f4add(f4add(f4scale(f4add(v, ldg4(bc + col)), m), ldg4(fc + (size_t)row * N + col)), ldg4(hbar + (size_t)n * N + col));
@@ -38,33 +38,28 @@ struct EpContentOut {               // any C
 };
 struct EpContentOut4 {              // C == 4: one lane owns the 4 clips of a cell -> also emits fcmean = mean_c out
     const float* bc; const int* cells; const float* fc; const float* hbar; float* out; float* fcmean;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_quads_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, const float4 (&v)[4]) {
+            const int n = row >> 2;
+            const float m = (float)cells[4 * (size_t)n + 3];
+            const float4 b4 = ldg4(bc + col), hb = ldg4(hbar + (size_t)n * N + col);
+            float4 sum = f4zero();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = t + 256 * it, cl = idx >> 5, c4 = (idx & 31) * 4;
-            const int n = (row_base >> 2) + cl, col = col_base + c4;
-            if (4 * n < M && col < N) {
-                const float m = (float)cells[4 * (size_t)n + 3];
-                const float4 b4 = ldg4(bc + col), hb = ldg4(hbar + (size_t)n * N + col);
-                float4 sum = f4zero();
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const size_t o = ((size_t)n * 4 + c) * N + col;
-                    const float4 v = ldg4(Cs + (cl * 4 + c) * GEMM_LDC + c4);
-                    const float4 r = f4add(f4add(f4scale(f4add(v, b4), m), ldg4(fc + o)), hb);
-                    stg4(out + o, r);
-                    sum = f4add(sum, r);
-                }
-                stg4(fcmean + (size_t)n * N + col, f4scale(sum, 0.25f));
+            for (int c = 0; c < 4; ++c) {
+                const size_t o = ((size_t)row + c) * N + col;
+                const float4 r = f4add(f4add(f4scale(f4add(v[c], b4), m), ldg4(fc + o)), hb);
+                stg4(out + o, r);
+                sum = f4add(sum, r);
             }
-        }
+            stg4(fcmean + (size_t)n * N + col, f4scale(sum, 0.25f));
+        });
     }
 };
 
 struct EpPlain {
     float* out;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
     }
 };
 
@@ -72,8 +67,8 @@ struct EpPlain {
 template <bool HAS_DFC>
 struct EpAddDout {                  // any C
     const float* dfc_out; const float* dmean; float* out; int C; float invC;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             float4 r = f4fma(ldg4(dmean + (size_t)(row / C) * N + col), invC, v);
             if (HAS_DFC) r = f4add(r, ldg4(dfc_out + (size_t)row * N + col));
             stg4(out + (size_t)row * N + col, r);
@@ -83,24 +78,20 @@ struct EpAddDout {                  // any C
 template <bool HAS_DFC>
 struct EpAddDout4 {                 // C == 4: also emits dhbar[n] = sum_c dout[n,c] (gradient of the gate term)
     const float* dfc_out; const float* dmean; float* out; float* dhbar;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_quads_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, const float4 (&v)[4]) {
+            const int n = row >> 2;
+            const float4 dm = ldg4(dmean + (size_t)n * N + col);
+            float4 sum = dm;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = t + 256 * it, cl = idx >> 5, c4 = (idx & 31) * 4;
-            const int n = (row_base >> 2) + cl, col = col_base + c4;
-            if (4 * n < M && col < N) {
-                const float4 dm = ldg4(dmean + (size_t)n * N + col);
-                float4 sum = dm;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const size_t o = ((size_t)n * 4 + c) * N + col;
-                    float4 r = f4fma(dm, 0.25f, ldg4(Cs + (cl * 4 + c) * GEMM_LDC + c4));
-                    if (HAS_DFC) { const float4 d = ldg4(dfc_out + o); r = f4add(r, d); sum = f4add(sum, d); }
-                    stg4(out + o, r);
-                }
-                stg4(dhbar + (size_t)n * N + col, sum);
+            for (int c = 0; c < 4; ++c) {
+                const size_t o = ((size_t)row + c) * N + col;
+                float4 r = f4fma(dm, 0.25f, v[c]);
+                if (HAS_DFC) { const float4 d = ldg4(dfc_out + o); r = f4add(r, d); sum = f4add(sum, d); }
+                stg4(out + o, r);
             }
-        }
+            stg4(dhbar + (size_t)n * N + col, sum);
+        });
     }
 };
 

@@ -75,75 +75,93 @@ __device__ __forceinline__ float4 f4sel(bool ok, float4 v) {
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-constexpr int GEMM_LDC = 132;           // row stride (floats) of the staged 128x128 accumulator tile
+constexpr int GEMM_LDW = 68;            // row stride (floats) of a wave's staged 32 x 64 accumulator chunk
 
-// Visit the staged tile row-major, one float4 per lane: 32 lanes cover one 512-byte row segment.
+// Visit a wave's staged chunk row-major, one float4 per lane: 16 lanes cover one 256-byte row segment.
 template <class F>
-__device__ __forceinline__ void tile_rows_f4(const float* Cs, int row_base, int col_base, int M, int N, int t, F f)
+__device__ __forceinline__ void chunk_rows_f4(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane, F f)
 {
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int idx = t + 256 * it, r = idx >> 5, c4 = (idx & 31) * 4;
-        const int row = row_base + r, col = col_base + c4;
-        if (row < M && col < N) f(row, col, ldg4(Cs + r * GEMM_LDC + c4));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = lane + 64 * it, r = idx >> 4, c4 = (idx & 15) * 4;
+        const int row = row0 + r, col = col0 + c4;
+        if (c4 < ncols && row < M && col < N) f(row, col, ldg4(Ws + r * GEMM_LDW + c4));
+    }
+}
+// Same chunk as 8 groups of 4 consecutive rows (row0 % 4 == 0): f(first_row, col, v[4]) -- one lane owns the 4 clips of a cell.
+template <class F>
+__device__ __forceinline__ void chunk_quads_f4(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane, F f)
+{
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = lane + 64 * it, g = idx >> 4, c4 = (idx & 15) * 4;
+        const int row = row0 + 4 * g, col = col0 + c4;
+        if (c4 < ncols && row < M && col < N) {
+            const float4 v[4] = {ldg4(Ws + (4 * g) * GEMM_LDW + c4), ldg4(Ws + (4 * g + 1) * GEMM_LDW + c4),
+                                 ldg4(Ws + (4 * g + 2) * GEMM_LDW + c4), ldg4(Ws + (4 * g + 3) * GEMM_LDW + c4)};
+            f(row, col, v);
+        }
     }
 }
 
 // ------------------------------------------------------------------ NT kernel
-// Epilogue protocol: void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const
-//   Cs is the 128 x 128 accumulator tile in LDS (row stride GEMM_LDC); t = threadIdx.x.
-template <class AM, class BM_, class EP>
-__global__ __launch_bounds__(256, 2)
-void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int tiles_n)
+// Epilogue protocol: void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const
+//   Ws is a wave-private 32 x ncols (64 or 32) piece of the accumulator tile in LDS (row stride GEMM_LDW) whose
+//   first element is C[row0][col0]; rows >= M / cols >= N must be skipped.  No workgroup barrier is involved:
+//   each wave transposes its own accumulators through its own LDS region and streams them out.
+// Tail handling: a grid of equal tiles runs ceil(tiles / slots) rounds, the last one mostly empty (3152 tiles on
+// 512 slots = 6.16 -> 7 rounds).  The first `main_tiles_m` row tiles are 128 rows; the remaining rows are cut into
+// 32-row "mini" tiles (one 32x32 MFMA tile per wave) so that the last round costs a quarter of a full one.
+template <bool MINI, bool KFULL, class AM, class BM_, class EP>
+__device__ __forceinline__ void gemm_nt_body(float* smem, const AM& am, const BM_& bm, const EP& ep, int M, int N, int K,
+                                             int row_base, int col_base)
 {
-    constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];      // 73,728 B >= 128 * GEMM_LDC * 4
+    // K-step 16: 40 KB of LDS per workgroup and <= 168 VGPRs -> 3 workgroups (3 waves per SIMD) per CU, which keeps the
+    // matrix pipe fed while one workgroup sits at its barrier or in its epilogue.
+    constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 4, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP;
     float* As = smem;
     float* Bs = smem + 2 * BM * LDT;
-
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the tiles_n column
-    // tiles of one row tile (which re-read the same A rows) are consecutive slots of one XCD's L2.
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
-    if (tm >= tiles_m) return;
-
-    const int t = threadIdx.x, lr = t >> 3, kq = (t & 7) * 4;
-    const int row_base = tm * BM, col_base = tn * BN;
+    const int tile_rows = MINI ? 32 : BM;
+    const int t = threadIdx.x, lr = t / KQ, kq = (t % KQ) * 4;
 
     // out-of-range rows are clamped: they only feed accumulator rows/columns that are never stored
-    typename AM::Row arow[4];
-    typename BM_::Row brow[4];
+    typename AM::Row arow[NP];
+    typename BM_::Row brow[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        arow[p] = am.row(min(row_base + lr + 32 * p, M - 1));
-        brow[p] = bm.row(min(col_base + lr + 32 * p, N - 1));
+    for (int p = 0; p < NP; ++p) {
+        arow[p] = am.row(min(row_base + (MINI ? (lr & 31) : lr + RPP * p), M - 1));
+        brow[p] = bm.row(min(col_base + lr + RPP * p, N - 1));
     }
 
     const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];
+    const int wrow = MINI ? 0 : wm * 64, wcol = MINI ? wave * 32 : wn * 64;
+    constexpr int NMI = MINI ? 1 : 2;
+    f32x16 acc[NMI][NMI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NMI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NMI; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra4[4], rb4[4];
+    float4 ra4[NP], rb4[NP];
     auto g_load = [&](int k0) {
         const int k = k0 + kq;
-        const bool kok = k < K;
-        const int kc = min(k, K - 4);
+        if (KFULL) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra4[p] = f4sel(kok, am.at(arow[p], kc));
-            rb4[p] = f4sel(kok, bm.at(brow[p], kc));
+            for (int p = 0; p < NP; ++p) { ra4[p] = am.at(arow[p], k); rb4[p] = bm.at(brow[p], k); }
+        } else {
+            const bool kok = k < K;
+            const int kc = min(k, K - 4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { ra4[p] = f4sel(kok, am.at(arow[p], kc)); rb4[p] = f4sel(kok, bm.at(brow[p], kc)); }
         }
     };
     auto s_store = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            stg4(As + buf * BM * LDT + (lr + 32 * p) * LDT + kq, ra4[p]);
-            stg4(Bs + buf * BN * LDT + (lr + 32 * p) * LDT + kq, rb4[p]);
+        for (int p = 0; p < NP; ++p) {
+            stg4(As + buf * BM * LDT + (lr + RPP * p) * LDT + kq, ra4[p]);
+            stg4(Bs + buf * BN * LDT + (lr + RPP * p) * LDT + kq, rb4[p]);
         }
     };
 
@@ -154,49 +172,84 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int tiles_m, int 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) g_load((kt + 1) * BK);
-        const float* ab = As + cur * BM * LDT + (wm * 64 + l31) * LDT + 4 * h;
-        const float* bb = Bs + cur * BN * LDT + (wn * 64 + l31) * LDT + 4 * h;
+        const float* ab = As + cur * BM * LDT + (wrow + l31) * LDT + 4 * h;
+        const float* bb = Bs + cur * BN * LDT + (wcol + l31) * LDT + 4 * h;
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             // lane half h supplies k = 8kg+4h+q at MFMA step q: A and B use the same k permutation
-            const float4 a0 = ldg4(ab + kg * 8), a1 = ldg4(ab + 32 * LDT + kg * 8);
-            const float4 b0 = ldg4(bb + kg * 8), b1 = ldg4(bb + 32 * LDT + kg * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            float4 a4[NMI], b4[NMI];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[0][0] = mfma32(av0[q], bv0[q], acc[0][0]);
-                acc[0][1] = mfma32(av0[q], bv1[q], acc[0][1]);
-                acc[1][0] = mfma32(av1[q], bv0[q], acc[1][0]);
-                acc[1][1] = mfma32(av1[q], bv1[q], acc[1][1]);
-            }
+            for (int i = 0; i < NMI; ++i) { a4[i] = ldg4(ab + i * 32 * LDT + kg * 8); b4[i] = ldg4(bb + i * 32 * LDT + kg * 8); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < NMI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NMI; ++j) {
+                        const float av = q == 0 ? a4[i].x : q == 1 ? a4[i].y : q == 2 ? a4[i].z : a4[i].w;
+                        const float bv = q == 0 ? b4[j].x : q == 1 ? b4[j].y : q == 2 ? b4[j].z : b4[j].w;
+                        acc[i][j] = mfma32(av, bv, acc[i][j]);
+                    }
         }
         if (kt + 1 < nk) s_store(cur ^ 1);
         __syncthreads();
     }
 
-    // stage the accumulators: C/D layout of a 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* Cs = smem;
+    // Epilogue: C/D layout of a 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each wave
+    // writes one 32-row slab of its tile to its private LDS region and reads it back row-major (float4 per lane).
+    float* Ws = smem + wave * (32 * GEMM_LDW);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < NMI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NMI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Cs[row * GEMM_LDC + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
-            }
-    __syncthreads();
-    ep.tile(Cs, row_base, col_base, M, N, t);
+            for (int r = 0; r < 16; ++r)
+                Ws[((r & 3) + 8 * (r >> 2) + 4 * h) * GEMM_LDW + ni * 32 + l31] = acc[mi][ni][r];
+        __builtin_amdgcn_wave_barrier();
+        ep.chunk(Ws, row_base + wrow + mi * 32, col_base + wcol, 32 * NMI, min(M, row_base + tile_rows), N, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
+
+template <bool KFULL, class AM, class BM_, class EP>
+__global__ __launch_bounds__(256, 3)
+void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m, int tiles_n, int main_blocks)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 20];      // 40,960 B >= 4 waves * 32 * GEMM_LDW * 4
+    if ((int)blockIdx.x < main_blocks) {
+        // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the tiles_n column
+        // tiles of one row tile (which re-read the same A rows) are consecutive slots of one XCD's L2.
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
+        if (tm >= main_tiles_m) return;
+        gemm_nt_body<false, KFULL>(smem, am, bm, ep, M, N, K, tm * 128, tn * 128);
+    } else {
+        const int id = blockIdx.x - main_blocks;
+        gemm_nt_body<true, KFULL>(smem, am, bm, ep, M, N, K, main_tiles_m * 128 + (id / tiles_n) * 32, (id % tiles_n) * 128);
+    }
+}
+
+constexpr int GEMM_SLOTS = 768;         // resident workgroups: 256 CUs x 3 (40 KB LDS, <= 168 VGPRs each)
 
 template <class AM, class BM_, class EP>
 static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, const EP& ep, int M, int N, int K)
 {
     if (M <= 0 || N <= 0) return 0;
     const int tiles_m = cdiv(M, 128), tiles_n = cdiv(N, 128);
-    const int blocks = cdiv(tiles_m, 8) * 8 * tiles_n;
-    hipLaunchKernelGGL((gemm_nt_kernel<AM, BM_, EP>), dim3(blocks), dim3(256), 0, st, am, bm, ep, M, N, K, tiles_m, tiles_n);
+    int main_tiles_m = tiles_m;
+    const int total = tiles_m * tiles_n;
+    const int full_rounds = total / GEMM_SLOTS;
+    if (full_rounds >= 1 && total % GEMM_SLOTS != 0 && (total % GEMM_SLOTS) < (3 * GEMM_SLOTS) / 4)
+        main_tiles_m = (full_rounds * GEMM_SLOTS) / tiles_n;         // whole rounds of 128-row tiles, rest as mini tiles
+    const int rem_rows = M - main_tiles_m * 128;
+    const int mini_blocks = rem_rows > 0 ? cdiv(rem_rows, 32) * tiles_n : 0;
+    const int main_blocks = cdiv(main_tiles_m, 8) * 8 * tiles_n;
+    if (K % 16 == 0)
+        hipLaunchKernelGGL((gemm_nt_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                           main_tiles_m, tiles_n, main_blocks);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                           main_tiles_m, tiles_n, main_blocks);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
@@ -204,11 +257,11 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
 // ------------------------------------------------------------------ TN kernel (weight gradients)
 // slab[z][I][J] = sum over rows m in split z of A[m][i] * B[m][j];  optional bias slab[z][I] = sum_m A[m][i].
 template <class AM, class BM_, bool BIAS>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 3)
 void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__ bias_slab,
                     int Mrows, int I, int J, int rows_per_split)
 {
-    constexpr int BI = 128, BJ = 128, BK = 32;
+    constexpr int BI = 128, BJ = 128, BK = 16, NP = BK / 8;          // 32 KB of LDS -> 3 workgroups per CU
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BI + BJ)];
     float* As = smem;
     float* Bs = smem + 2 * BK * BI;
@@ -230,10 +283,10 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum = 0.f;
 
-    float4 ra4[4], rb4[4];
+    float4 ra4[NP], rb4[NP];
     auto g_load = [&](int m0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int m = m0 + lk + 8 * p;
             const bool ok = m < m_end;
             const int mc = min(m, Mrows - 1);
@@ -243,7 +296,7 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
     };
     auto s_store = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             stg4(As + buf * BK * BI + (lk + 8 * p) * BI + c4, ra4[p]);
             stg4(Bs + buf * BK * BJ + (lk + 8 * p) * BJ + c4, rb4[p]);
         }
@@ -297,11 +350,11 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
 static inline int tn_splits(int Mrows, int I, int J)
 {
     const int tiles = cdiv(I, 128) * cdiv(J, 128);
-    int s = cdiv(512, tiles);
+    int s = cdiv(GEMM_SLOTS, tiles);
     const int max_s = cdiv(Mrows, 256);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 192) s = 192;
     return s;
 }
 

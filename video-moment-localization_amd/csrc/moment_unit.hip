@@ -9,8 +9,8 @@ namespace smin {
 
 struct EpMomentOut {                // mu = (acc + bcat) * m + fm
     const float* bcat; const int* cells; const float* fm; float* out;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             const float m = (float)cells[4 * (size_t)row + 3];
             stg4(out + (size_t)row * N + col, f4add(f4scale(f4add(v, ldg4(bcat + col)), m), ldg4(fm + (size_t)row * N + col)));
         });
@@ -19,8 +19,8 @@ struct EpMomentOut {                // mu = (acc + bcat) * m + fm
 
 struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean
     float* dx1; float* dmean; int D;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) {
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             float* dst = col < D ? dx1 + col : dmean + (col - D);
             stg4(dst + (size_t)row * D, v);
         });

@@ -43,8 +43,8 @@ __global__ void unpack_cells_kernel(const float* __restrict__ packed, const int*
 
 struct EpStore {
     float* out;
-    __device__ __forceinline__ void tile(const float* Cs, int row_base, int col_base, int M, int N, int t) const {
-        tile_rows_f4(Cs, row_base, col_base, M, N, t, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
     }
 };
 
@@ -60,9 +60,9 @@ extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int N
     (void)Nq;
     const size_t M = (size_t)N * C;
     // content unit bwd: 2 x [M][dl] + TN slabs (<= 64 splits) + attention slabs + gate partials
-    size_t content = 3 * M * dl + 2 * M * 32 + 2 * (size_t)64 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 64 * D;
+    size_t content = 3 * M * dl + 2 * M * 32 + 2 * (size_t)192 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 64 * D;
     // moment unit bwd: dX1 [N][D] + slabs [64][D][2D] + bias slabs
-    size_t moment = (size_t)N * D + (size_t)64 * ((size_t)D * 2 * D + D);
+    size_t moment = (size_t)N * D + (size_t)192 * ((size_t)D * 2 * D + D);
     // boundary / score: per-row partials
     size_t other = (size_t)N + 8 * (size_t)B * 64 * D + (size_t)N * 4;
     size_t fl = content > moment ? content : moment;
