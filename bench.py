@@ -121,15 +121,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
-
     import models
-    from vml_amd import functional as Fn, loss_fn
+    from vml_amd import distributed as D, functional as Fn, loss_fn
     models.vml_amd._lib.load()
+    D.init(backend="nccl", device=dev)                           # nccl == RCCL on ROCm (xGMI inside the node)
 
     cfg = WORKLOADS[args.workload]
     T, L, C, D, dl, layers, Din, Nq, Hh, B = cfg
@@ -138,10 +133,7 @@ def main():
     torch.manual_seed(43)                                    # config/*.yml: seed 43, default initialisation
     model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
-    net = model
-    if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(model, device_ids=[local_rank], bucket_cap_mb=8, gradient_as_bucket_view=True)
+    net = D.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)
     n_valid = int(batch["moment_mask"].sum().item())
 
@@ -157,8 +149,7 @@ def main():
         return loss
 
     def fence():
-        if dist is not None:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -172,15 +163,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     Fn.RECORD_EVENTS = False
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        nv = torch.tensor([n_valid], dtype=torch.float64, device=dev)
-        dist.all_reduce(nv)
-        n_valid_total = int(nv.item())
-    else:
-        n_valid_total = n_valid
+    elapsed = D.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
+    n_valid_total = int(D.sum_over_ranks(n_valid, dev))
 
     # dominant kernel: moment-unit forward GEMM  mu = X[N, 2D] @ Wcat[D, 2D]^T  (one launch per layer per step)
     durs = [s.elapsed_time(e) for (name, s, e) in Fn.KERNEL_EVENTS if name == "moment_unit_fwd"]
@@ -219,8 +203,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

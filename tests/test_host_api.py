@@ -1,0 +1,154 @@
+"""CPU: host-side contract of the drop-in (no GPU needed).
+ - the module surface mirrors the reference's models.py (names, ctor defaults, state_dict keys / shapes);
+ - default initialisation reproduces the reference's under the same seed (checked against the golden
+   state_dict produced from the reference; and against /root/reference when it is present);
+ - libsmin_hip.so loads and exports every symbol include/smin_hip.h declares;
+ - the product path fails loudly on CPU tensors (no CPU fallback);
+ - the packed cell layout is built correctly."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_module_surface_and_signatures():
+    import models
+    names = ["SMIN", "SMI", "Attention", "Backbone", "BoundaryUnit", "ContentAttention", "ContentUnit", "Localization",
+             "MomentUnit", "ProposalGeneration", "QueryEncoder", "VideoEncoder", "compute_content_matrix"]
+    for n in names:
+        assert hasattr(models, n), n
+    assert list(inspect.signature(models.SMIN.__init__).parameters)[1:] == [
+        "T", "L", "C", "D", "dl", "num_smi_layers", "input_video_dim", "max_query_length", "lstm_hidden_size", "device"]
+    assert list(inspect.signature(models.SMIN.forward).parameters)[1:] == [
+        "video_features", "video_mask", "query_features", "query_mask", "length_mask", "moment_mask"]
+    # defaults used by the reference's simpletest.py
+    d = lambda f: {k: v.default for k, v in inspect.signature(f).parameters.items() if v.default is not inspect._empty}
+    assert d(models.Backbone.__init__) == dict(T=64, d=512, input_video_dim=1024, max_query_length=13, lstm_hidden_size=256, device='cpu')
+    assert d(models.ProposalGeneration.__init__) == dict(T=64, L=16, C=4, device='cpu')
+    assert d(models.VideoEncoder.__init__) == dict(T=64, d=512, input_video_dim=1024, device='cpu')
+    assert d(models.QueryEncoder.__init__) == dict(max_query_length=13, lstm_hidden_size=256)
+
+
+@pytest.mark.parametrize("name", H.TINY)
+def test_state_dict_contract_matches_reference(name):
+    import models
+    cfg, sd, *_ = H.split_tiny(H.load_npz(name))
+    m = models.SMIN(cfg["T"], cfg["L"], cfg["C"], cfg["D"], cfg["dl"], cfg["layers"], cfg["Din"], cfg["Nq"], cfg["H"])
+    mine = m.state_dict()
+    assert list(mine.keys()) == list(sd.keys())                      # same names, same order, no buffers (no Wc)
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
+    assert {k: tuple(v.shape) for k, v in mine.items()} == H.smin_shapes(cfg["T"], cfg["L"], cfg["C"], cfg["D"], cfg["dl"],
+                                                                          cfg["layers"], cfg["Din"], cfg["Nq"], cfg["H"])
+    m.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models.py"), reason="reference tree only exists in the build container")
+def test_default_init_identical_to_reference():
+    import importlib.util
+    import models
+    spec = importlib.util.spec_from_file_location("ref_models_for_init", "/root/reference/models.py")
+    ref = importlib.util.module_from_spec(spec)
+    import sys
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(ref)
+    args = (32, 8, 4, 32, 16, 2, 24, 5, 16)
+    torch.manual_seed(43)
+    a = ref.SMIN(*args).state_dict()
+    torch.manual_seed(43)
+    b = models.SMIN(*args).state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    import models
+    header = open(os.path.join(ROOT, "include", "smin_hip.h")).read()
+    declared = set(re.findall(r"\b(smin_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(models.vml_amd._lib.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in smin_hip.h but not exported"
+    assert declared == set(models.vml_amd._lib.SIGNATURES), "ctypes table and header disagree"
+    loaded = models.vml_amd._lib.load()
+    assert loaded.smin_abi_version() == 1 and loaded.smin_target_arch() == b"gfx950"
+    assert loaded.smin_workspace_bytes(1000, 2, 4, 512, 128, 20) > 0
+
+
+def test_product_path_fails_loudly_on_cpu():
+    import models
+    from oracle import smin_oracle as O
+    m = models.SMIN(16, 8, 4, 32, 16, 1, 24, 5, 16)
+    b = O.synthetic_batch(2, 16, 8, 5, 24, with_labels=False)
+    with pytest.raises(models.vml_amd._lib.SminHipError, match="no CPU fallback"):
+        m(*H.model_inputs(b))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "video-moment-localization_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                for ln in open(os.path.join(dp, f)).read().splitlines():
+                    assert not (("import" in ln) and ("oracle" in ln)), (f, ln)
+    assert "oracle" not in open(os.path.join(ROOT, "models.py")).read()
+
+
+def test_cell_layout():
+    import models
+    CellLayout = models.vml_amd.CellLayout
+    g = torch.Generator().manual_seed(0)
+    mm = torch.rand(3, 6, 6, generator=g) > 0.5
+    lay = CellLayout.from_mask(mm)
+    assert lay.N == int(mm.sum())
+    cells = lay.cells
+    assert cells.dtype == torch.int32 and cells.shape == (lay.N, 4) and bool((cells[:, 3] == 1).all())
+    key = cells[:, 0].long() * 36 + cells[:, 1].long() * 6 + cells[:, 2].long()
+    assert bool((key[1:] > key[:-1]).all())                          # sorted by (b, i, j)
+    rp = lay.row_ptr
+    assert rp.shape == (3 * 6 + 1,) and int(rp[-1]) == lay.N
+    for b in range(3):
+        for i in range(6):
+            n0, n1 = int(rp[b * 6 + i]), int(rp[b * 6 + i + 1])
+            assert n1 - n0 == int(mm[b, i].sum())
+            assert bool((cells[n0:n1, 0] == b).all()) and bool((cells[n0:n1, 1] == i).all())
+    assert bool((lay.cellmap[mm] == torch.arange(lay.N, dtype=torch.int32)).all()) and bool((lay.cellmap[~mm] == -1).all())
+    dense = torch.randn(3, 6, 6, 5, generator=g)
+    assert torch.equal(lay.unpack(lay.pack(dense)), dense * mm.unsqueeze(-1))
+    full = CellLayout.all_cells(mm)
+    assert full.N == 3 * 36 and torch.equal(full.cells[:, 3].bool().view(3, 6, 6), mm)
+
+
+def test_compute_content_matrix_matches_golden():
+    import models
+    z = H.load_npz("g4_wc")
+    for key in [k[6:] for k in z.files if k.startswith("start/")]:
+        T, L, C = (int(v) for v in key.split("_"))
+        Wc = models.compute_content_matrix(T, L, C)
+        size = torch.from_numpy(z["size/" + key]).long()
+        start = torch.from_numpy(z["start/" + key]).long()
+        val = torch.from_numpy(z["val/" + key])
+        t = torch.arange(T)
+        ref = ((t >= start.unsqueeze(-1)) & (t < (start + size).unsqueeze(-1))).float() * val.unsqueeze(-1)
+        assert torch.equal(Wc, ref), key
+
+
+def test_loss_and_metric_restatements_match_oracle_and_golden():
+    import models
+    from oracle import smin_oracle as O
+    cfg, sd, batch, out, _, loss_ref = H.split_tiny(H.load_npz("g1_r4"))
+    loss = models.vml_amd.loss_fn(out["pm"], batch["ym"], batch["sm"], batch["moment_mask"], out["ps"], batch["ys"], batch["ss"],
+                                  out["pe"], batch["ye"], batch["se"], out["pa"], batch["ya"], batch["length_mask"])
+    assert abs(loss.item() - loss_ref) < 1e-6
+    z = H.load_npz("g6_ious")
+    got = models.vml_amd.compute_ious(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))
+    for k, v in zip(z["keys"], z["vals"]):
+        assert got[str(k)] == float(v)
+    assert got == O.compute_ious(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))

@@ -8,7 +8,7 @@ per-cell work done by hand-written HIP kernels for gfx950 behind the C ABI in
 The directory name contains '-' so it cannot be imported by name; the repo-root ``models.py``
 loads it under the module name ``vml_amd``.
 """
-from . import _lib  # noqa: F401
+from . import _lib, distributed  # noqa: F401
 from .cells import CellLayout  # noqa: F401
 from .modules import (  # noqa: F401
     SMIN, SMI, Attention, Backbone, BoundaryUnit, ContentAttention, ContentUnit, Localization,
