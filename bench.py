@@ -122,9 +122,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import models
-    from vml_amd import distributed as D, functional as Fn, loss_fn
+    from vml_amd import distributed as dp, functional as Fn, loss_fn
     models.vml_amd._lib.load()
-    D.init(backend="nccl", device=dev)                           # nccl == RCCL on ROCm (xGMI inside the node)
+    dp.init(backend="nccl", device=dev)                           # nccl == RCCL on ROCm (xGMI inside the node)
 
     cfg = WORKLOADS[args.workload]
     T, L, C, D, dl, layers, Din, Nq, Hh, B = cfg
@@ -133,7 +133,7 @@ def main():
     torch.manual_seed(43)                                    # config/*.yml: seed 43, default initialisation
     model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
-    net = D.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
+    net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)
     n_valid = int(batch["moment_mask"].sum().item())
 
@@ -149,7 +149,7 @@ def main():
         return loss
 
     def fence():
-        D.barrier()
+        dp.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -163,8 +163,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     Fn.RECORD_EVENTS = False
-    elapsed = D.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
-    n_valid_total = int(D.sum_over_ranks(n_valid, dev))
+    elapsed = dp.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
+    n_valid_total = int(dp.sum_over_ranks(n_valid, dev))
 
     # dominant kernel: moment-unit forward GEMM  mu = X[N, 2D] @ Wcat[D, 2D]^T  (one launch per layer per step)
     durs = [s.elapsed_time(e) for (name, s, e) in Fn.KERNEL_EVENTS if name == "moment_unit_fwd"]

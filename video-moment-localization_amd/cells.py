@@ -16,9 +16,12 @@ class CellLayout:
         self.bidx, self.iidx, self.jidx = idx[:, 0], idx[:, 1], idx[:, 2]
 
     @staticmethod
-    def _build(present, flag):
+    def _build(present, flag, N=None):
         B, L, _ = present.shape
-        idx = present.nonzero()                                   # (N, 3) sorted by (b, i, j); one host sync
+        if N is None:
+            idx = present.nonzero()                               # (N, 3) sorted by (b, i, j); one host sync
+        else:
+            idx = torch.nonzero_static(present, size=N)           # count already known: no sync
         N = idx.shape[0]
         m = flag[idx[:, 0], idx[:, 1], idx[:, 2]].to(torch.int32).unsqueeze(1)
         cells = torch.cat([idx.to(torch.int32), m], dim=1).contiguous()
@@ -39,6 +42,12 @@ class CellLayout:
         mm = moment_mask != 0
         return CellLayout._build(torch.ones_like(mm), mm)
 
+    @staticmethod
+    def begin(moment_mask):
+        """Start building the mask-driven layout without blocking the host: the cell count is copied to pinned
+        memory asynchronously; call .finish() after enqueueing independent work (the backbone)."""
+        return _PendingLayout(moment_mask)
+
     # dense (B, L, L, ...) <-> packed (N, ...) through torch indexing (differentiable; seams only)
     def pack(self, dense):
         return dense[self.bidx, self.iidx, self.jidx].contiguous()
@@ -47,3 +56,20 @@ class CellLayout:
         out = packed.new_zeros((self.B, self.L, self.L) + tuple(packed.shape[1:]))
         out[self.bidx, self.iidx, self.jidx] = packed
         return out
+
+
+class _PendingLayout:
+    def __init__(self, moment_mask):
+        self.mm = moment_mask != 0
+        self.event = None
+        if self.mm.is_cuda:
+            self.host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            self.host.copy_(self.mm.sum().reshape(1), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def finish(self):
+        if self.event is None:
+            return CellLayout._build(self.mm, self.mm)
+        self.event.synchronize()                                  # waits only for work queued before the count
+        return CellLayout._build(self.mm, self.mm, int(self.host[0]))

@@ -50,14 +50,34 @@ class QueryEncoder(nn.Module):
         self.lstm = nn.LSTM(input_size=300, hidden_size=lstm_hidden_size, num_layers=2, bidirectional=True, batch_first=True)
 
     def forward(self, query_features, query_mask):
-        B = query_features.shape[0]
-        length = query_mask.reshape(B, -1).sum(1)
-        packed = nn.utils.rnn.pack_padded_sequence(query_features, length.to('cpu'), batch_first=True, enforce_sorted=False)
-        out, _ = self.lstm(packed)
-        fw, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=self.max_query_length)
+        """Same result as the reference's pack_padded_sequence / pad_packed_sequence round trip, but on padded
+        tensors with the lengths kept on the device: the reference copies them to the host here
+        (models.py:52), a sync that stalls the whole pipeline once per step.  Forward direction: positions past
+        a sample's length never influence earlier outputs and are zeroed afterwards.  Backward direction: each
+        sequence is reversed in place (gather), run forwards, and reversed back."""
+        B, Nq, _ = query_features.shape
+        H = self.lstm_hidden_size
+        length = query_mask.reshape(B, -1).sum(1).long()
+        t = torch.arange(Nq, device=query_features.device).unsqueeze(0)
+        valid = (t < length.unsqueeze(1)).to(query_features.dtype).unsqueeze(-1)          # (B, Nq, 1)
+        rev = (length.unsqueeze(1) - 1 - t).clamp(min=0).unsqueeze(-1)                     # (B, Nq, 1)
+        h0 = query_features.new_zeros(1, B, H)
+        x = query_features
+        for layer in range(2):
+            outs = []
+            for sfx in ("", "_reverse"):
+                w = [getattr(self.lstm, f"{n}_l{layer}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                xin = x if not sfx else torch.gather(x, 1, rev.expand(-1, -1, x.shape[-1])) * valid
+                y = torch._VF.lstm(xin, (h0, h0), w, True, 1, 0.0, self.training, False, True)[0]
+                if sfx:
+                    y = torch.gather(y, 1, rev.expand(-1, -1, H))
+                outs.append(y * valid)
+            x = torch.cat(outs, dim=2)
+        fw = x
+        if Nq < self.max_query_length:
+            fw = torch.nn.functional.pad(fw, (0, 0, 0, self.max_query_length - Nq))
         fw = fw.contiguous()
-        H = fw.shape[2] // 2
-        last = (length.long() - 1).view(B, 1, 1).expand(B, 1, H)
+        last = (length - 1).clamp(min=0).view(B, 1, 1).expand(B, 1, H)
         fs = torch.cat([fw[:, :, :H].gather(1, last).view(B, H), fw[:, 0, H:]], dim=1)
         return fs, fw
 
@@ -293,8 +313,9 @@ class SMIN(nn.Module):
         self.localization = Localization(D)
 
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
+        pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
         f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
-        layout = CellLayout.from_mask(moment_mask)                 # work is driven by moment_mask (SURVEY 8a-0 caveat)
+        layout = pending.finish()                                  # the only host sync of a step; hidden behind the backbone
         fc, fm, fb = self.pgm.forward_packed(f, layout)
         for smi in self.smis:
             fc, fm, fb = smi.forward_packed(fc, fm, fb, fw, fs, query_mask, length_mask, layout)
