@@ -46,8 +46,8 @@ int smin_proposal_map_fwd(void* stream, const float* f, const int32_t* cells, in
                           float* fc, float* fm, float* fb, void* ws, size_t ws_bytes /* >= 8*B*(T+1)*D */);
 /* df [B][T][D] = d/df of the three outputs (any of dfc/dfm/dfb may be NULL = zero).  ws_bytes >= 4*B*T*D. */
 int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, const float* dfb,
-                          const int32_t* cells, const int32_t* cellmap, int N, int B, int T, int L, int C, int D,
-                          float* df, void* ws, size_t ws_bytes);
+                          const int32_t* cells, const int32_t* row_ptr, const int32_t* cellmap,
+                          int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes);
 
 /* ---- Gated moment feature shared by ContentUnit (models.py:272-274) and BoundaryUnit (models.py:191):
  *   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]          hbar [N][D]

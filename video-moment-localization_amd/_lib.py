@@ -18,7 +18,7 @@ SIGNATURES = {
     "smin_target_arch": [],
     "smin_workspace_bytes": [_i] * 6,
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
-    "smin_proposal_map_bwd": [_vp] * 6 + [_i] * 6 + [_vp, _vp, _sz],
+    "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz],
     "smin_gate_fwd": [_vp] * 4 + [_i] * 2 + [_vp],
     "smin_gate_bwd": [_vp] * 5 + [_i] * 4 + [_vp] * 2 + [_vp, _sz],
     "smin_content_unit_fwd": [_vp] * 5 + [_i] * 7 + [_vp] * 9 + [_vp] * 4,

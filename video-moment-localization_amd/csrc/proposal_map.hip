@@ -77,7 +77,7 @@ __global__ void boundary_pool_fwd_kernel(const float* __restrict__ f, int T, int
 }
 
 // E[b][t][:] = sum over clips starting at t of g/cs  -  sum over clips ending at t of g/cs,
-// g = m * (dfc[n][c][:] + dfm[n][:] / C).  One workgroup per (b, t).
+// g = m * (dfc[n][c][:] + dfm[n][:] / C).  One workgroup per (b, t); deterministic (pure gather).
 __global__ __launch_bounds__(128)
 void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* __restrict__ dfm,
                                     const int* __restrict__ cells, const int* __restrict__ cellmap,
@@ -91,7 +91,9 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = f4zero();
 
-    auto add_event = [&](int i, int w, int c, int cs, float sign) {
+    // with_m: the mean-path gradient dfm/C is the same for all clips of a cell, and the clips tile the window back to
+    // back, so it survives only at the first clip's start and the last clip's end (interior start/end pairs cancel).
+    auto add_event = [&](int i, int w, int c, int cs, float sign, bool with_m) {
         const int j = i + w - 1;
         if (j >= L) return;
         const int n = cmap[i * L + j];
@@ -104,7 +106,7 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
             if (d < D) {
                 float4 g = f4zero();
                 if (dfc) g = ldg4(dfc + ((size_t)n * C + c) * D + d);
-                if (dfm) g = f4fma(ldg4(dfm + (size_t)n * D + d), invC, g);
+                if (dfm && with_m) g = f4fma(ldg4(dfm + (size_t)n * D + d), invC, g);
                 acc[k] = f4fma(g, sc, acc[k]);
             }
         }
@@ -116,14 +118,14 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
         if (cs == 1) lo = 1;
         lo = max(lo, c / r + 1);
         hi = min(hi, L - i);
-        for (int w = lo; w <= hi; ++w) add_event(i, w, c, cs, sign);
+        for (int w = lo; w <= hi; ++w) add_event(i, w, c, cs, sign, sign < 0.f && c + 1 == min(C, w * r));
     };
 
     const int imax = min(L - 1, t / r);
     for (int i = 0; i <= imax; ++i) {
         const int base = t - i * r;                         // offset of frame t inside the window of row i
         if (base == 0) {                                    // clip 0 of every width starts here
-            for (int w = 1; w <= L - i; ++w) add_event(i, w, 0, max(1, (w * r) / C), 1.0f);
+            for (int w = 1; w <= L - i; ++w) add_event(i, w, 0, max(1, (w * r) / C), 1.0f, true);
         } else {
             for (int c = 1; c < C; ++c)                     // clip c >= 1 starts at t:  c * cs == base
                 if (base % c == 0) for_widths(i, c, base / c, 1.0f);
@@ -182,8 +184,8 @@ extern "C" int smin_proposal_map_fwd(void* stream, const float* f, const int32_t
 }
 
 extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, const float* dfb,
-                                        const int32_t* cells, const int32_t* cellmap, int N, int B, int T, int L, int C, int D,
-                                        float* df, void* ws, size_t ws_bytes)
+                                        const int32_t* cells, const int32_t* row_ptr, const int32_t* cellmap,
+                                        int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && L >= 1 && T >= L && T % L == 0 && C >= 1 && D <= 2048);

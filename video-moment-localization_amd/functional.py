@@ -64,7 +64,7 @@ class ProposalMapFn(Function):
         ref = dfc if dfc is not None else dfm if dfm is not None else dfb
         df = ref.new_empty((B, T, D))
         _, wp, wn = _ws(4 * B * T * D, df.device)
-        call("smin_proposal_map_bwd", stream(), ptr(dfc), ptr(dfm), ptr(dfb), ptr(layout.cells), ptr(layout.cellmap),
+        call("smin_proposal_map_bwd", stream(), ptr(dfc), ptr(dfm), ptr(dfb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
              layout.N, B, T, L, C, D, ptr(df), wp, wn)
         return df, None, None, None, None
 
