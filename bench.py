@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only")
+    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the dense NT contractions")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +125,7 @@ def main():
     import models
     from vml_amd import distributed as dp, functional as Fn, loss_fn
     models.vml_amd._lib.load()
+    models.vml_amd.set_gemm_mode(args.gemm)
     dp.init(backend="nccl", device=dev)                           # nccl == RCCL on ROCm (xGMI inside the node)
 
     cfg = WORKLOADS[args.workload]

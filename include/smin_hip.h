@@ -34,6 +34,13 @@ extern "C" {
 #define SMIN_HIP_ABI_VERSION 1
 
 int smin_abi_version(void);
+/* Arithmetic of the dense "NT" contractions (forward maps and input gradients):
+ *   0 (default) exact fp32 on v_mfma_f32_32x32x2_f32;
+ *   1 split-bf16: operands split into hi+lo bf16 on the fly, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with
+ *     fp32 accumulation (~1e-5 relative on a dot product, 5.3x the fp32 matrix rate).
+ * Process-wide; returns 0 or -1 for an unknown mode. */
+int smin_set_gemm_mode(int mode);
+int smin_get_gemm_mode(void);
 /* "gfx950" -- the only code object in the library */
 const char* smin_target_arch(void);
 /* bytes of scratch any single call below may need for N cells (C, D, dl, Nq, B as given) */

@@ -232,3 +232,54 @@ def test_gradients_deterministic(dev):
         snaps.append({k: p.grad.clone() for k, p in m.named_parameters() if "smis" in k or "localization" in k})
     for k in snaps[0]:
         assert torch.equal(snaps[0][k], snaps[1][k]), k          # fixed-order reductions: bitwise reproducible
+
+
+# ---------------------------------------------------------------- split-bf16 ("bf16x3") contraction mode
+@pytest.fixture()
+def bf16x3():
+    import models
+    models.vml_amd.set_gemm_mode("bf16x3")
+    yield
+    models.vml_amd.set_gemm_mode("f32")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 512), (515, 512, 128), (4096, 512, 1024), (37, 20, 16)])
+def test_gemm_nt_engine_bf16x3(dev, bf16x3, M, N, K):
+    from vml_amd.functional import gemm_nt
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    ref = (a.double() @ b.double().t())
+    got = gemm_nt(a.to(dev), b.to(dev)).cpu().double()
+    rel = ((got - ref).abs().max() / ref.abs().max()).item()
+    print("bf16x3 gemm", (M, N, K), "max err / max |C|", rel)
+    assert rel < 2e-5            # ~2^-16 per product; fp32 mode reaches ~1e-7 here
+
+
+@pytest.mark.parametrize("name", ["charades", "anet_t256"])
+def test_full_size_against_golden_bf16x3(dev, bf16x3, name):
+    """Same golden check as the fp32 mode with the tolerance this arithmetic earns: scores 1e-4 (required 1e-3)."""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    z = H.load_npz("g5_" + name)
+    T, L, C, D, dl, layers, Din, Nq, Hh = H.FULL[name]
+    B, seed = int(z["cfg"][-2]), int(z["cfg"][-1])
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.3)
+    m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+    batch = O.synthetic_batch(B, T, L, Nq, Din, seed=seed)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    pm, ps, pe, pa = m(*H.model_inputs(b))
+    for k, v in (("pm", pm), ("ps", ps), ("pe", pe), ("pa", pa)):
+        err = (v.detach().cpu() - torch.from_numpy(z["out/" + k])).abs().max().item()
+        print("bf16x3", name, k, "max abs err", err)
+        assert err < 1e-4, (k, err)
+    loss = loss_fn(pm, b["ym"], b["sm"], b["moment_mask"], ps, b["ys"], b["ss"], pe, b["ye"], b["se"], pa, b["ya"], b["length_mask"])
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    norms = dict(zip([str(s) for s in z["grad_names"]], z["grad_norms"]))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        got = p.grad.double().norm().item()
+        worst = max(worst, abs(got - norms[k]) / (norms[k] + 1e-12))
+        assert abs(got - norms[k]) <= 5e-3 * norms[k] + 1e-7, (k, got, norms[k])
+    print("bf16x3", name, "worst grad-norm deviation", worst)

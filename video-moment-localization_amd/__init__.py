@@ -9,6 +9,7 @@ The directory name contains '-' so it cannot be imported by name; the repo-root 
 loads it under the module name ``vml_amd``.
 """
 from . import _lib, distributed  # noqa: F401
+from ._lib import get_gemm_mode, set_gemm_mode  # noqa: F401
 from .cells import CellLayout  # noqa: F401
 from .modules import (  # noqa: F401
     SMIN, SMI, Attention, Backbone, BoundaryUnit, ContentAttention, ContentUnit, Localization,

@@ -16,6 +16,8 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 SIGNATURES = {
     "smin_abi_version": [],
     "smin_target_arch": [],
+    "smin_set_gemm_mode": [_i],
+    "smin_get_gemm_mode": [],
     "smin_workspace_bytes": [_i] * 6,
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
     "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz],
@@ -107,3 +109,17 @@ def check(rc, name):
 
 def call(name, *args):
     check(getattr(load(), name)(*args), name)
+
+
+GEMM_MODES = {"f32": 0, "bf16x3": 1}
+
+
+def set_gemm_mode(mode):
+    """Arithmetic of the dense forward / input-gradient contractions: "f32" (exact fp32 MFMA, default) or "bf16x3"
+    (split-bf16 on the bf16 matrix cores, fp32 accumulate; ~1e-5 relative)."""
+    check(load().smin_set_gemm_mode(GEMM_MODES[mode]), "smin_set_gemm_mode")
+
+
+def get_gemm_mode():
+    m = load().smin_get_gemm_mode()
+    return [k for k, v in GEMM_MODES.items() if v == m][0]

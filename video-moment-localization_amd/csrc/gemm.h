@@ -144,34 +144,29 @@ __device__ __forceinline__ void gemm_nt_body(float* smem, const AM& am, const BM
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra4[NP], rb4[NP];
-    auto g_load = [&](int k0) {
-        const int k = k0 + kq;
+    // Two register stages: the loads of tile kt+3 are issued while tile kt is computed and consumed two iterations later.
+    struct Stage { float4 a[NP], b[NP]; };
+    const int nk = (K + BK - 1) / BK;
+    auto g_load = [&](Stage& st, int kt) {
+        const int k = min(kt, nk - 1) * BK + kq;                   // past-the-end tiles reload the last one (never used)
         if (KFULL) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) { ra4[p] = am.at(arow[p], k); rb4[p] = bm.at(brow[p], k); }
+            for (int p = 0; p < NP; ++p) { st.a[p] = am.at(arow[p], k); st.b[p] = bm.at(brow[p], k); }
         } else {
             const bool kok = k < K;
             const int kc = min(k, K - 4);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) { ra4[p] = f4sel(kok, am.at(arow[p], kc)); rb4[p] = f4sel(kok, bm.at(brow[p], kc)); }
+            for (int p = 0; p < NP; ++p) { st.a[p] = f4sel(kok, am.at(arow[p], kc)); st.b[p] = f4sel(kok, bm.at(brow[p], kc)); }
         }
     };
-    auto s_store = [&](int buf) {
+    auto s_store = [&](const Stage& st, int buf) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            stg4(As + buf * BM * LDT + (lr + RPP * p) * LDT + kq, ra4[p]);
-            stg4(Bs + buf * BN * LDT + (lr + RPP * p) * LDT + kq, rb4[p]);
+            stg4(As + buf * BM * LDT + (lr + RPP * p) * LDT + kq, st.a[p]);
+            stg4(Bs + buf * BN * LDT + (lr + RPP * p) * LDT + kq, st.b[p]);
         }
     };
-
-    const int nk = (K + BK - 1) / BK;
-    g_load(0);
-    s_store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) g_load((kt + 1) * BK);
+    auto compute = [&](int cur) {
         const float* ab = As + cur * BM * LDT + (wrow + l31) * LDT + 4 * h;
         const float* bb = Bs + cur * BN * LDT + (wcol + l31) * LDT + 4 * h;
 #pragma unroll
@@ -191,8 +186,25 @@ __device__ __forceinline__ void gemm_nt_body(float* smem, const AM& am, const BM
                         acc[i][j] = mfma32(av, bv, acc[i][j]);
                     }
         }
-        if (kt + 1 < nk) s_store(cur ^ 1);
+    };
+
+    Stage s0, s1;
+    g_load(s0, 0);
+    s_store(s0, 0);
+    g_load(s0, 1);
+    g_load(s1, 2);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);                                                // tile kt
+        if (kt + 1 < nk) s_store(s0, 1);                           // tile kt+1
+        g_load(s0, kt + 3);
         __syncthreads();
+        if (kt + 1 < nk) {
+            compute(1);                                            // tile kt+1
+            if (kt + 2 < nk) s_store(s1, 0);                       // tile kt+2
+            g_load(s1, kt + 4);
+            __syncthreads();
+        }
     }
 
     // Epilogue: C/D layout of a 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each wave
@@ -229,6 +241,163 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m,
     }
 }
 
+// ------------------------------------------------------------------ NT kernel, split-bf16 ("bf16x3") variant
+// fp32 operands are split on the fly into hi = bf16(x) and lo = bf16(x - hi) and every 16-deep block is accumulated
+// as  hi*hi + hi*lo + lo*hi  with v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped lo*lo term and the
+// residual of the split are ~2^-16 relative per product, i.e. ~1e-5 on a dot product instead of fp32's ~1e-7, at
+// 16/3 = 5.3x the matrix rate of the exact fp32 MFMA.  Same tiling, loaders and epilogues as gemm_nt_body.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo)
+{
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const __bf16 hb = (__bf16)x[q];
+        h[q] = __builtin_bit_cast(unsigned short, hb);
+        l[q] = __builtin_bit_cast(unsigned short, (__bf16)(x[q] - (float)hb));
+    }
+    hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool MINI, bool KFULL, class AM, class BM_, class EP>
+__device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const BM_& bm, const EP& ep, int M, int N, int K,
+                                                int row_base, int col_base)
+{
+    // LDS: four bf16 images per buffer (A_hi, A_lo, B_hi, B_lo), rows of 16 k-values padded to 24 (48 B: the 16-byte
+    // fragment reads of 16 consecutive rows fall on 16 different slots).  2 buffers x 4 x 128 x 48 B = 49,152 B.
+    constexpr int BM = 128, BN = 128, BK = 16, RS = 24, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP, IMG = BM * RS;
+    unsigned short* lds = reinterpret_cast<unsigned short*>(smem);
+    const int tile_rows = MINI ? 32 : BM;
+    const int t = threadIdx.x, lr = t / KQ, kq = (t % KQ) * 4;
+
+    typename AM::Row arow[NP];
+    typename BM_::Row brow[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        arow[p] = am.row(min(row_base + (MINI ? (lr & 31) : lr + RPP * p), M - 1));
+        brow[p] = bm.row(min(col_base + lr + RPP * p, N - 1));
+    }
+    const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wrow = MINI ? 0 : wm * 64, wcol = MINI ? wave * 32 : wn * 64;
+    constexpr int NMI = MINI ? 1 : 2;
+    f32x16 acc[NMI][NMI];
+#pragma unroll
+    for (int a = 0; a < NMI; ++a)
+#pragma unroll
+        for (int b = 0; b < NMI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // Two register stages: the loads of tile kt+3 are issued while tile kt is computed and are consumed two
+    // iterations later -- one iteration of this kernel (12 bf16 MFMAs per wave) is far shorter than an HBM round trip.
+    struct Stage { float4 a[NP], b[NP]; };
+    const int nk = (K + BK - 1) / BK;
+    auto g_load = [&](Stage& st, int kt) {
+        const int k = min(kt, nk - 1) * BK + kq;                   // past-the-end tiles reload the last one (never used)
+        if (KFULL) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { st.a[p] = am.at(arow[p], k); st.b[p] = bm.at(brow[p], k); }
+        } else {
+            const bool kok = k < K;
+            const int kc = min(k, K - 4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { st.a[p] = f4sel(kok, am.at(arow[p], kc)); st.b[p] = f4sel(kok, bm.at(brow[p], kc)); }
+        }
+    };
+    auto s_store = [&](const Stage& st, int buf) {
+        unsigned short* base = lds + buf * 4 * IMG;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            uint2 hi, lo;
+            const int o = (lr + RPP * p) * RS + kq;
+            split_bf16x4(st.a[p], hi, lo);
+            *reinterpret_cast<uint2*>(base + o) = hi;
+            *reinterpret_cast<uint2*>(base + IMG + o) = lo;
+            split_bf16x4(st.b[p], hi, lo);
+            *reinterpret_cast<uint2*>(base + 2 * IMG + o) = hi;
+            *reinterpret_cast<uint2*>(base + 3 * IMG + o) = lo;
+        }
+    };
+    auto compute = [&](int cur) {
+        const unsigned short* base = lds + cur * 4 * IMG;
+        const unsigned short* ab = base + (wrow + l31) * RS + 8 * h;          // lane (row, h) holds k = 8h .. 8h+7
+        const unsigned short* bb = base + 2 * IMG + (wcol + l31) * RS + 8 * h;
+        bf16x8 ah[NMI], al[NMI], bh[NMI], bl[NMI];
+#pragma unroll
+        for (int i = 0; i < NMI; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * RS);
+            al[i] = *reinterpret_cast<const bf16x8*>(ab + IMG + i * 32 * RS);
+            bh[i] = *reinterpret_cast<const bf16x8*>(bb + i * 32 * RS);
+            bl[i] = *reinterpret_cast<const bf16x8*>(bb + IMG + i * 32 * RS);
+        }
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int j = 0; j < NMI; ++j) {
+                acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+                acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+            }
+    };
+
+    Stage s0, s1;
+    g_load(s0, 0);
+    s_store(s0, 0);
+    g_load(s0, 1);
+    g_load(s1, 2);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);                                                // tile kt
+        if (kt + 1 < nk) s_store(s0, 1);                           // tile kt+1
+        g_load(s0, kt + 3);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            compute(1);                                            // tile kt+1
+            if (kt + 2 < nk) s_store(s1, 0);                       // tile kt+2
+            g_load(s1, kt + 4);
+            __syncthreads();
+        }
+    }
+
+    float* Ws = smem + wave * (32 * GEMM_LDW);
+#pragma unroll
+    for (int mi = 0; mi < NMI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NMI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ws[((r & 3) + 8 * (r >> 2) + 4 * h) * GEMM_LDW + ni * 32 + l31] = acc[mi][ni][r];
+        __builtin_amdgcn_wave_barrier();
+        ep.chunk(Ws, row_base + wrow + mi * 32, col_base + wcol, 32 * NMI, min(M, row_base + tile_rows), N, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool KFULL, class AM, class BM_, class EP>
+__global__ __launch_bounds__(256, 3)
+void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m, int tiles_n, int main_blocks)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * 4 * 128 * 24 / 2];      // 49,152 B
+    if ((int)blockIdx.x < main_blocks) {
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
+        if (tm >= main_tiles_m) return;
+        gemm_nt_x3_body<false, KFULL>(smem, am, bm, ep, M, N, K, tm * 128, tn * 128);
+    } else {
+        const int id = blockIdx.x - main_blocks;
+        gemm_nt_x3_body<true, KFULL>(smem, am, bm, ep, M, N, K, main_tiles_m * 128 + (id / tiles_n) * 32, (id % tiles_n) * 128);
+    }
+}
+
+// 0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3) for the NT contractions; set by smin_set_gemm_mode()
+extern int g_gemm_mode;
+
 constexpr int GEMM_SLOTS = 768;         // resident workgroups: 256 CUs x 3 (40 KB LDS, <= 168 VGPRs each)
 
 template <class AM, class BM_, class EP>
@@ -244,7 +413,14 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
     const int rem_rows = M - main_tiles_m * 128;
     const int mini_blocks = rem_rows > 0 ? cdiv(rem_rows, 32) * tiles_n : 0;
     const int main_blocks = cdiv(main_tiles_m, 8) * 8 * tiles_n;
-    if (K % 16 == 0)
+    if (g_gemm_mode == 1) {
+        if (K % 16 == 0)
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                               main_tiles_m, tiles_n, main_blocks);
+        else
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                               main_tiles_m, tiles_n, main_blocks);
+    } else if (K % 16 == 0)
         hipLaunchKernelGGL((gemm_nt_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
                            main_tiles_m, tiles_n, main_blocks);
     else

@@ -4,6 +4,8 @@
 
 namespace smin {
 
+int g_gemm_mode = 0;
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int P)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,6 +55,13 @@ struct EpStore {
 using namespace smin;
 
 extern "C" int smin_abi_version(void) { return SMIN_HIP_ABI_VERSION; }
+extern "C" int smin_set_gemm_mode(int mode)
+{
+    if (mode != 0 && mode != 1) return -1;
+    g_gemm_mode = mode;
+    return 0;
+}
+extern "C" int smin_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" const char* smin_target_arch(void) { return "gfx950"; }
 
 extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int Nq)
