@@ -70,13 +70,18 @@ int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, const float
  *   (so that  W_q(c_hat) . W_k(what)^T  ==  c_hat . Mq^T + uq  -- the per-cell dl x dl projection folds away)
  *   qmask [B][Nq] fp32 0/1;  hbar from smin_gate_fwd.
  * Outputs: fc_out [N][C][D], fcmean [N][D] = mean_c fc_out (consumed by the moment unit);
- * saved for backward: chat [N*C][dl], cchat [N*C][dl]. */
+ * saved for backward: chat [N*C][dl], cchat [N*C][dl].
+ * last != 0 (final SMI layer: nothing consumes fc_out itself, models.py:372-375): fc_out is not written (may be
+ * NULL), cchat receives mean_c cchat [N][dl] and linear_c runs on N rows; fcmean_in [N][D] = mean_c fc (the
+ * previous layer's fcmean, or the proposal map's f_m) is required. */
 int smin_content_unit_fwd(void* stream, const float* fc, const float* hbar, const int32_t* cells, const int32_t* row_ptr,
                           int N, int B, int L, int C, int D, int dl, int Nq,
                           const float* Wch, const float* bch, const float* Mq, const float* uq,
                           const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
+                          const float* fcmean_in, int last,
                           float* fc_out, float* fcmean, float* chat, float* cchat);
-/* Backward.  dfc_out may be NULL (last layer: only the moment unit consumes fc_out, through fcmean).
+/* Backward.  dfc_out may be NULL (last layer: only the moment unit consumes fc_out, through fcmean); pass the
+ * same `last` as in forward (then dfc_out must be NULL and cchat is the [N][dl] clip mean).
  * WcT [dl][D] and WchT [D][dl] are transposed copies of the weights.
  * Gradients: dfc [N][C][D], dhbar [N][D], dWch [dl][D], dbch [dl], dMq [B][Nq][dl], duq [B][Nq],
  * dwhat [B][Nq][dl], dshat [B][dl], dWc [D][dl], dbc [D]. */
@@ -87,7 +92,7 @@ int smin_content_unit_bwd(void* stream, const float* dfc_out, const float* dfcme
                           const float* what, const float* shat, const float* qmask, const float* WcT,
                           const float* chat, const float* cchat,
                           float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
-                          float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes);
+                          float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes, int last);
 
 /* ---- BoundaryUnit.forward, the map-sized part (models.py:190-194):
  *   fbm[b,i,:] = sum_j A_b[b,i,j] * hbar[(b,i,j),:]

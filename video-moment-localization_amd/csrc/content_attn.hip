@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2)
 void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                                   const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                                   const float* __restrict__ shat, const float* __restrict__ qmask,
-                                  float* __restrict__ cchat, int dl, int Nq, int cells_per_chunk, float scale)
+                                  float* __restrict__ cchat, int dl, int Nq, int cells_per_chunk, float scale, int mean_only)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -236,6 +236,7 @@ void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __r
     if (n_begin >= s1) return;
     const int n_end = min(s1, n_begin + cells_per_chunk);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    const float invC = 1.0f / C;
     AttnLds<DL> s(smem_dyn, false);
     stage_sample<DL>(s, false, Mq, uq, what, shat, qmask, b, dl, Nq);
     __syncthreads();
@@ -257,7 +258,14 @@ void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __r
                 fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
             }
             const int d = 8 * kg + 4 * h;
-            if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+            if (!mean_only) {
+                if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+            } else {                                                // mean over the clips of the quad (padding lanes hold 0)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = (o4[q] + nb<1>(o4[q]) + nb<2>(o4[q]) + nb<3>(o4[q])) * invC;
+                if (g.ok && (lane & 3) == 0 && d < dl)
+                    stg4(cchat + (size_t)(g.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+            }
             if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +280,7 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
                                   const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                                   const float* __restrict__ shat, const float* __restrict__ qmask,
                                   float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
-                                  int dl, int Nq, int cells_per_chunk, float scale)
+                                  int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int LDM = AttnLds<DL>::LDM, KG = DL / 8;
@@ -301,7 +309,7 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int d = 8 * kg + 4 * h;
-            const float4 g4 = ldg4(dcchat + (size_t)g.row * dl + min(d, dl - 4));
+            const float4 g4 = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(d, dl - 4));
             const bool ok = g.ok && d < dl;
             const float gv[4] = {ok ? g4.x : 0.f, ok ? g4.y : 0.f, ok ? g4.z : 0.f, ok ? g4.w : 0.f};
 #pragma unroll
@@ -432,20 +440,32 @@ void content_attn_wordgrad_kernel(const float* __restrict__ chat, const float* _
     float sh[DT], du = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) sh[dt] = 0.f;
-    for (int row2 = rb; row2 < re; row2 += 2) {                  // wave-uniform trip count: MFMA needs every lane live
-        const bool ok = row2 + h < re;
-        const size_t row = (size_t)min(row2 + h, re - 1);
-        const float gs = ok ? dS[row * 32 + l31] : 0.f, ps = ok ? P[row * 32 + l31] : 0.f;
-        du += gs;
+    // two row pairs per iteration: all loads of an iteration are issued before the first MFMA consumes them
+    for (int row2 = rb; row2 < re; row2 += 4) {                  // wave-uniform trip count: MFMA needs every lane live
+        float gs[2], ps[2], cv[2][DT], dv[2][DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = min(32 * dt + l31, dl - 1);
-            const bool dok = ok && 32 * dt + l31 < dl;
-            const float cv = dok ? chat[row * dl + d] : 0.f;
-            const float dv = dok ? da[row * dl + d] : 0.f;
-            sh[dt] += dv;
-            aM[dt] = mfma32(gs, cv, aM[dt]);
-            aW[dt] = mfma32(ps, dv, aW[dt]);
+        for (int u = 0; u < 2; ++u) {
+            const bool ok = row2 + 2 * u + h < re;
+            const size_t row = (size_t)min(row2 + 2 * u + h, re - 1);
+            gs[u] = ok ? dS[row * 32 + l31] : 0.f;
+            ps[u] = ok ? P[row * 32 + l31] : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = min(32 * dt + l31, dl - 1);
+                const bool dok = ok && 32 * dt + l31 < dl;
+                cv[u][dt] = dok ? chat[row * dl + d] : 0.f;
+                dv[u][dt] = dok ? da[row * dl + d] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            du += gs[u];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                sh[dt] += dv[u][dt];
+                aM[dt] = mfma32(gs[u], cv[u][dt], aM[dt]);
+                aW[dt] = mfma32(ps[u], dv[u][dt], aW[dt]);
+            }
         }
     }
     const size_t slab_sz = (size_t)2 * 32 * dl + dl + 32;
@@ -486,23 +506,23 @@ __global__ void content_attn_reduce_kernel(const float* __restrict__ slab, int d
 // ---- launchers --------------------------------------------------------------------------------------------------
 template <int DL>
 static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
-                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask, float* cchat, int dl, int Nq)
+                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask, float* cchat, int dl, int Nq, int mean_only)
 {
     int cpc, mc; chunking(L, &cpc, &mc);
     hipLaunchKernelGGL((content_attn_fwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(false), st, chat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, cchat, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
+                       Mq, uq, what, shat, qmask, cchat, dl, Nq, cpc, 1.0f / sqrtf((float)dl), mean_only);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* cchat, int dl, int Nq)
+                            float* cchat, int dl, int Nq, int mean_only)
 {
-    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
-    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
-    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
-    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
+    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
+    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
+    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
 }
 
 size_t content_attn_bwd_ws_floats(int M, int B, int dl)
@@ -513,7 +533,7 @@ size_t content_attn_bwd_ws_floats(int M, int B, int dl)
 template <int DL>
 static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq)
+                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell)
 {
     int cpc, mc; chunking(L, &cpc, &mc);
     float* da = ws;
@@ -521,7 +541,7 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
     float* P = dS + (size_t)M * 32;
     float* slab = P + (size_t)M * 32;
     hipLaunchKernelGGL((content_attn_bwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(true), st, chat, dcchat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
+                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL((content_attn_wordgrad_kernel<DL>), dim3(ATTN_SPLITS, B), dim3(256), 0, st, chat, da, dS, P, row_ptr, L, C, dl, ATTN_SPLITS, slab);
     SMIN_LAUNCH_CHECK();
@@ -533,12 +553,12 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq)
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell)
 {
-    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
-    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
-    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
-    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq);
+    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
+    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
+    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
+    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
 }
 
 }  // namespace smin

@@ -56,6 +56,24 @@ struct EpContentOut4 {              // C == 4: one lane owns the 4 clips of a ce
     }
 };
 
+// last layer: only mean_c of the output is consumed ->  fcmean = m * (cmean Wc^T + bc) + mean_c fc + hbar   (rows = cells)
+struct EpLastMean {
+    const float* bc; const int* cells; const float* fcmean_in; const float* hbar; float* fcmean;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            const float m = (float)cells[4 * (size_t)row + 3];
+            const size_t o = (size_t)row * N + col;
+            stg4(fcmean + o, f4add(f4add(f4scale(f4add(v, ldg4(bc + col)), m), ldg4(fcmean_in + o)), ldg4(hbar + o)));
+        });
+    }
+};
+struct EpScale {                    // out = acc * s
+    float* out; float s;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, f4scale(v, s)); });
+    }
+};
+
 struct EpPlain {
     float* out;
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
@@ -126,6 +144,7 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
                                      int N, int B, int L, int C, int D, int dl, int Nq,
                                      const float* Wch, const float* bch, const float* Mq, const float* uq,
                                      const float* what, const float* shat, const float* qmask, const float* Wc, const float* bc,
+                                     const float* fcmean_in, int last,
                                      float* fc_out, float* fcmean, float* chat, float* cchat)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -134,8 +153,10 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
     const int M = N * C;
     int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, C}, M, dl, D);
     if (rc) return rc;
-    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq);
+    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, last);
     if (rc) return rc;
+    if (last)                       // cchat holds mean_c cchat [N][dl]; a quarter of the rows, and fc_out is never written
+        return launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpLastMean{bc, cells, fcmean_in, hbar, fcmean}, N, D, dl);
     if (C == 4)
         return launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpContentOut4{bc, cells, fc, hbar, fc_out, fcmean}, M, D, dl);
     rc = launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpContentOut{bc, cells, fc, hbar, fc_out, C}, M, D, dl);
@@ -155,7 +176,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
                                  const float* what, const float* shat, const float* qmask, const float* WcT,
                                  const float* chat, const float* cchat,
                                  float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
-                                 float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes)
+                                 float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes, int last)
 {
     const int M = N * C;
     const float invC = 1.0f / C;
@@ -164,23 +185,33 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     auto take = [&](size_t n) { float* p = w + off; off += (n + 3) & ~(size_t)3; return p; };
     float* dcchat = take((size_t)M * dl);
     float* dchat = take((size_t)M * dl);
-    const int sp1 = tn_splits(M, D, dl), sp2 = tn_splits(M, dl, D);
+    const int sp1 = tn_splits(last ? N : M, D, dl), sp2 = tn_splits(M, dl, D);
     float* slab1 = take((size_t)sp1 * D * dl); float* bslab1 = take((size_t)sp1 * D);
     float* slab2 = take((size_t)sp2 * dl * D); float* bslab2 = take((size_t)sp2 * dl);
     float* aws = take(content_attn_bwd_ws_floats(M, B, dl));
     SMIN_REQUIRE(off * sizeof(float) <= ws_bytes);
     const DoutEffMat<true, HAS_DFC> dout{dfc_out, dfcmean, cells, C, D, invC};
 
-    // (a) dcchat = (dout * m) @ Wc          [M, dl], contraction over D
-    int rc = launch_gemm_nt(st, dout, PlainMat{WcT, D}, EpPlain{dcchat}, M, dl, D);
-    if (rc) return rc;
-    // (b) dWc[D, dl] = (dout*m)^T @ cchat ; dbc = colsum(dout*m)
-    rc = launch_gemm_tn(st, dout, PlainMat{cchat, dl}, slab1, bslab1, M, D, dl, sp1);
-    if (rc) return rc;
+    int rc;
+    if (last) {
+        // only mean_c of the output was consumed: the gradient row dfcmean/C is shared by the clips of a cell, so
+        // (a) and (b) run on N rows with the saved clip mean (cchat = mean_c cchat [N][dl]) instead of N*C rows.
+        rc = launch_gemm_nt(st, MaskedRowsMat{dfcmean, D, cells}, PlainMat{WcT, D}, EpScale{dcchat, invC}, N, dl, D);
+        if (rc) return rc;
+        rc = launch_gemm_tn(st, MaskedRowsMat{dfcmean, D, cells}, PlainMat{cchat, dl}, slab1, bslab1, N, D, dl, sp1);
+        if (rc) return rc;
+    } else {
+        // (a) dcchat = (dout * m) @ Wc          [M, dl], contraction over D
+        rc = launch_gemm_nt(st, dout, PlainMat{WcT, D}, EpPlain{dcchat}, M, dl, D);
+        if (rc) return rc;
+        // (b) dWc[D, dl] = (dout*m)^T @ cchat ; dbc = colsum(dout*m)
+        rc = launch_gemm_tn(st, dout, PlainMat{cchat, dl}, slab1, bslab1, M, D, dl, sp1);
+        if (rc) return rc;
+    }
     rc = launch_reduce_slabs(st, slab1, dWc, D * dl, sp1); if (rc) return rc;
     rc = launch_reduce_slabs(st, bslab1, dbc, D, sp1); if (rc) return rc;
     // (c) attention core backward -> dchat (already multiplied by m: masked cells write 0)
-    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq);
+    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last);
     if (rc) return rc;
     // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl;  dhbar = sum_c dout (gate term)
     if (C == 4) {
@@ -208,14 +239,15 @@ extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const f
                                      const float* what, const float* shat, const float* qmask, const float* WcT,
                                      const float* chat, const float* cchat,
                                      float* dfc, float* dhbar, float* dWch, float* dbch, float* dMq, float* duq,
-                                     float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes)
+                                     float* dwhat, float* dshat, float* dWc, float* dbc, void* ws, size_t ws_bytes, int last)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SMIN_REQUIRE(!(last && dfc_out));                           // "last" means nothing consumed fc_out itself
     SMIN_REQUIRE(D % 4 == 0 && dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     if (dfc_out)
         return content_unit_bwd_impl<true>(st, dfc_out, dfcmean, fc, cells, row_ptr, N, B, L, C, D, dl, Nq, WchT, Mq, uq, what, shat, qmask,
-                                           WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes);
+                                           WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes, last);
     return content_unit_bwd_impl<false>(st, nullptr, dfcmean, fc, cells, row_ptr, N, B, L, C, D, dl, Nq, WchT, Mq, uq, what, shat, qmask,
-                                        WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes);
+                                        WcT, chat, cchat, dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, dWc, dbc, ws, ws_bytes, last);
 }

@@ -10,9 +10,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __res
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < P; ++z) s += slab[(size_t)z * n + idx];
-    out[idx] = s;
+    // eight independent partial sums keep eight loads in flight (a single running sum is one HBM round trip per slab);
+    // the association is fixed, so the result is still bitwise reproducible.
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= P; z += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += slab[(size_t)(z + u) * n + idx];
+    }
+    for (; z < P; ++z) s[0] += slab[(size_t)z * n + idx];
+    out[idx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 int launch_reduce_slabs(hipStream_t st, const float* slab, float* out, int n, int P)

@@ -104,19 +104,25 @@ class ContentUnitFn(Function):
     Outputs: fc_out [N,C,D], fcmean [N,D]."""
 
     @staticmethod
-    def forward(ctx, fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc, layout):
+    def forward(ctx, fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc, layout, fcmean_in=None):
+        """fcmean_in (= mean_c fc) marks the last SMI layer: nothing consumes fc_out there (models.py:372-375), so
+        linear_c and its gradients run on the clip means (N rows instead of N*C) and fc_out is returned empty."""
         fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc = map(_c, (fc, hbar, Wch, bch, Mq, uq, what, shat, qmask, Wc, bc))
         N, C, D = fc.shape
         B, Nq, dl = what.shape
-        fc_out = torch.empty_like(fc)
+        last = fcmean_in is not None
+        fcmean_in = _c(fcmean_in)
+        fc_out = fc.new_empty((0, C, D)) if last else torch.empty_like(fc)
         fcmean = fc.new_empty((N, D))
         chat = fc.new_empty((N * C, dl))
-        cchat = fc.new_empty((N * C, dl))
+        cchat = fc.new_empty((N if last else N * C, dl))
         call("smin_content_unit_fwd", stream(), ptr(fc), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr), N, B, layout.L, C, D, dl, Nq,
              ptr(Wch), ptr(bch), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(Wc), ptr(bc),
-             ptr(fc_out), ptr(fcmean), ptr(chat), ptr(cchat))
+             ptr(fcmean_in), int(last), None if last else ptr(fc_out), ptr(fcmean), ptr(chat), ptr(cchat))
         ctx.save_for_backward(fc, Wch, Mq, uq, what, shat, qmask, Wc, chat, cchat)
-        ctx.layout = layout
+        ctx.layout, ctx.last = layout, last
+        if last:
+            ctx.mark_non_differentiable(fc_out)
         return fc_out, fcmean
 
     @staticmethod
@@ -125,7 +131,7 @@ class ContentUnitFn(Function):
         layout = ctx.layout
         N, C, D = fc.shape
         B, Nq, dl = what.shape
-        dfc_out = _c(dfc_out)
+        dfc_out = None if ctx.last else _c(dfc_out)
         dfcmean = _c(dfcmean) if dfcmean is not None else fc.new_zeros((N, D))
         WchT, WcT = Wch.t().contiguous(), Wc.t().contiguous()
         dfc, dhbar = torch.empty_like(fc), fc.new_empty((N, D))
@@ -140,8 +146,9 @@ class ContentUnitFn(Function):
             call("smin_content_unit_bwd", stream(), ptr(dfc_out), ptr(dfcmean), ptr(fc), ptr(layout.cells), ptr(layout.row_ptr),
                  N, B, layout.L, C, D, dl, Nq, ptr(WchT), ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(WcT),
                  ptr(chat), ptr(cchat), ptr(dfc), ptr(dhbar), ptr(dWch), ptr(dbch), ptr(dMq), ptr(duq), ptr(dwhat), ptr(dshat),
-                 ptr(dWc), ptr(dbc), wp, wn)
-        return dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None
+                 ptr(dWc), ptr(dbc), wp, wn, int(ctx.last))
+        # fcmean_in is mean_c fc by contract: its gradient (dfcmean) is already folded into dfc as dfcmean / C per clip
+        return dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None, None
 
 
 class BoundaryReduceFn(Function):

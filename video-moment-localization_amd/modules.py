@@ -210,7 +210,7 @@ class ContentUnit(nn.Module):
         self.linear_c = nn.Linear(dl, D)
         self.attn_layer = ContentAttention(dl)
 
-    def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout):
+    def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout, fcmean_in=None):
         qm = _rows(query_mask)
         what = self.linear_w_hat(f_w) * qm.unsqueeze(-1)
         shat = self.linear_s_hat(f_s)
@@ -219,7 +219,7 @@ class ContentUnit(nn.Module):
         Mq = torch.matmul(kb, self.attn_layer.W_q.weight)
         uq = torch.matmul(kb, self.attn_layer.W_q.bias)
         return ContentUnitFn.apply(fc, hbar, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
-                                   self.linear_c.weight, self.linear_c.bias, layout)
+                                   self.linear_c.weight, self.linear_c.bias, layout, fcmean_in)
 
     def forward(self, f_c, f_w, f_s, f_m, query_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
@@ -259,16 +259,18 @@ class SMI(nn.Module):
         self.boundary_unit = BoundaryUnit(D)
         self.moment_unit = MomentUnit(D)
 
-    def forward_packed(self, fc, fm, f_b, f_w, f_s, query_mask, length_mask, layout):
+    def forward_packed(self, fc, fm, f_b, f_w, f_s, query_mask, length_mask, layout, fcmean_in=None):
+        """fcmean_in = mean_c fc marks the final layer of a stack (its content output is consumed only through the
+        clip mean); the returned content tensor is then empty."""
         hbar = GateFn.apply(fm, f_s, layout)                      # sigmoid(fm*fs)*fm, shared by both units
-        cu, cumean = self.content_unit.forward_packed(fc, hbar, f_w, f_s, query_mask, layout)
+        cu, cumean = self.content_unit.forward_packed(fc, hbar, f_w, f_s, query_mask, layout, fcmean_in)
         bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, hbar, query_mask, length_mask, layout)
         mu = self.moment_unit.forward_packed(cumean, fm, bu, layout)
-        return cu, mu, bu
+        return cu, mu, bu, cumean
 
     def forward(self, f_c, f_m, f_b, f_w, f_s, query_mask, length_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
-        cu, mu, bu = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_b, f_w, f_s, query_mask, length_mask, layout)
+        cu, mu, bu, _ = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_b, f_w, f_s, query_mask, length_mask, layout)
         return layout.unpack(cu), layout.unpack(mu), bu
 
 
@@ -317,6 +319,8 @@ class SMIN(nn.Module):
         f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
         layout = pending.finish()                                  # the only host sync of a step; hidden behind the backbone
         fc, fm, fb = self.pgm.forward_packed(f, layout)
-        for smi in self.smis:
-            fc, fm, fb = smi.forward_packed(fc, fm, fb, fw, fs, query_mask, length_mask, layout)
+        fcmean = fm                                                # mean_c fc: the map's f_m, then each layer's clip mean
+        for k, smi in enumerate(self.smis):
+            last = k == len(self.smis) - 1                        # the last layer's content output feeds nothing but its mean
+            fc, fm, fb, fcmean = smi.forward_packed(fc, fm, fb, fw, fs, query_mask, length_mask, layout, fcmean if last else None)
         return self.localization.forward_packed(fm, fb, length_mask, layout)
