@@ -274,7 +274,7 @@ void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __r
 
 // ---- backward ---------------------------------------------------------------------------------------------------
 template <int DL>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 1)
 void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
                                   const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                                   const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,

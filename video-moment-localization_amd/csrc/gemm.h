@@ -459,34 +459,29 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum = 0.f;
 
-    float4 ra4[NP], rb4[NP];
-    auto g_load = [&](int m0) {
+    // Two register stages (see gemm_nt_body): row descriptors and operands of tile kt+3 are requested while tile kt
+    // is computed; the virtual-matrix rows change every tile here, so their lookups are part of the prefetch.
+    struct Stage { float4 a[NP], b[NP]; };
+    const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
+    auto g_load = [&](Stage& st, int kt) {
+        const int m0 = m_begin + min(kt, max(nk - 1, 0)) * BK;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int m = m0 + lk + 8 * p;
             const bool ok = m < m_end;
             const int mc = min(m, Mrows - 1);
-            ra4[p] = f4sel(ok, am.at(am.row(mc), ia));
-            rb4[p] = f4sel(ok, bm.at(bm.row(mc), jb));
+            st.a[p] = f4sel(ok, am.at(am.row(mc), ia));
+            st.b[p] = f4sel(ok, bm.at(bm.row(mc), jb));
         }
     };
-    auto s_store = [&](int buf) {
+    auto s_store = [&](const Stage& st, int buf) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            stg4(As + buf * BK * BI + (lk + 8 * p) * BI + c4, ra4[p]);
-            stg4(Bs + buf * BK * BJ + (lk + 8 * p) * BJ + c4, rb4[p]);
+            stg4(As + buf * BK * BI + (lk + 8 * p) * BI + c4, st.a[p]);
+            stg4(Bs + buf * BK * BJ + (lk + 8 * p) * BJ + c4, st.b[p]);
         }
     };
-
-    const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
-    if (nk > 0) {
-        g_load(m_begin);
-        s_store(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) g_load(m_begin + (kt + 1) * BK);
+    auto compute = [&](int cur) {
         const float* ab = As + cur * BK * BI + wm * 64 + l31;
         const float* bb = Bs + cur * BK * BJ + wn * 64 + l31;
 #pragma unroll
@@ -504,8 +499,27 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) bsum += col[kk * BI];
         }
-        if (kt + 1 < nk) s_store(cur ^ 1);
+    };
+
+    Stage s0, s1;
+    if (nk > 0) {
+        g_load(s0, 0);
+        s_store(s0, 0);
+        g_load(s0, 1);
+        g_load(s1, 2);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) s_store(s0, 1);
+        g_load(s0, kt + 3);
         __syncthreads();
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) s_store(s1, 0);
+            g_load(s1, kt + 4);
+            __syncthreads();
+        }
     }
 
     float* out = slab + (size_t)z * I * J;
