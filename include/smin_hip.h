@@ -105,6 +105,25 @@ int smin_boundary_reduce_bwd(void* stream, const float* dfbm, const float* Ab, c
                              const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int D,
                              float* dAb, float* dhbar);
 
+/* ---- BoundaryUnit.forward, whole unit (models.py:164-196) with its word attention Attention.forward (models.py:137-154):
+ *   out = (A_b f_b) * lm + f_b + sum_j A_b[i,j] hbar[(i,j)],  A_b = softmax(mask(bq bq^T / sqrt(D))) * lm,
+ *   bq = f_b * (softmax(mask(W_q f_b . (W_k f_w)^T / sqrt(D))) f_w * lm + f_s).
+ * fb [B][L][D], fw [B][Nq][D], fs [B][D], qmask [B][Nq], lmask [B][L] fp32 0/1; Wq, Wk [D][D] (+ biases).
+ * Saved for backward (caller-allocated): Qb, baq, bqv [B][L][D], Kb [B][Nq][D], P [B][L][Nq], A [B][L][L]. */
+int smin_boundary_unit_fwd(void* stream, const float* fb, const float* fw, const float* fs, const float* hbar,
+                           const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int Nq, int D,
+                           const float* Wq, const float* bq, const float* Wk, const float* bk,
+                           const float* qmask, const float* lmask,
+                           float* out, float* Qb, float* Kb, float* P, float* baq, float* bqv, float* A);
+/* WqT, WkT: transposed weights.  Gradients: dfb, dfw, dfs, dhbar [N][D], dWq, dbq, dWk, dbk.
+ * ws_bytes >= 4 * (2*B*L*L + 3*B*L*D + B*L*Nq + B*Nq*D + 2*64*(D*D + D)). */
+int smin_boundary_unit_bwd(void* stream, const float* dout, const float* fb, const float* fw, const float* fs, const float* hbar,
+                           const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int Nq, int D,
+                           const float* WqT, const float* WkT, const float* qmask, const float* lmask,
+                           const float* Qb, const float* Kb, const float* P, const float* baq, const float* bqv, const float* A,
+                           float* dfb, float* dfw, float* dfs, float* dhbar, float* dWq, float* dbq, float* dWk, float* dbk,
+                           void* ws, size_t ws_bytes);
+
 /* ---- MomentUnit.forward (models.py:288-303): two 1x1 convs fused into one K = 2D contraction
  *   mu[n,:] = m * ( [fb[b,i]*fb[b,j] | fcmean[n]] @ Wcat^T + bcat ) + fm[n,:]
  * Wcat [D][2D] = [conv_layer_fb.weight | conv_layer_fc.weight], bcat [D] = sum of the two biases. */

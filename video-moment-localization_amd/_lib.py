@@ -27,6 +27,8 @@ SIGNATURES = {
     "smin_content_unit_bwd": [_vp] * 6 + [_i] * 7 + [_vp] * 9 + [_vp] * 10 + [_vp, _sz, _i],
     "smin_boundary_reduce_fwd": [_vp] * 5 + [_i] * 4 + [_vp],
     "smin_boundary_reduce_bwd": [_vp] * 6 + [_i] * 4 + [_vp] * 2,
+    "smin_boundary_unit_fwd": [_vp] * 7 + [_i] * 5 + [_vp] * 6 + [_vp] * 7,
+    "smin_boundary_unit_bwd": [_vp] * 8 + [_i] * 5 + [_vp] * 4 + [_vp] * 6 + [_vp] * 8 + [_vp, _sz],
     "smin_moment_unit_fwd": [_vp] * 5 + [_i] * 4 + [_vp] * 3,
     "smin_moment_unit_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz],
     "smin_score_map_fwd": [_vp] * 4 + [_i] * 4 + [_vp] * 7,

@@ -178,6 +178,44 @@ class BoundaryReduceFn(Function):
         return dAb, dhbar, None
 
 
+class BoundaryUnitFn(Function):
+    """BoundaryUnit.forward with its word attention (reference models.py:137-196), all in HIP."""
+
+    @staticmethod
+    def forward(ctx, fb, fw, fs, hbar, Wq, bq, Wk, bk, qmask, lmask, layout):
+        fb, fw, fs, hbar, Wq, bq, Wk, bk, qmask, lmask = map(_c, (fb, fw, fs, hbar, Wq, bq, Wk, bk, qmask, lmask))
+        B, L, D = fb.shape
+        Nq = fw.shape[1]
+        out = torch.empty_like(fb)
+        Qb, baq, bqv = torch.empty_like(fb), torch.empty_like(fb), torch.empty_like(fb)
+        Kb = torch.empty_like(fw)
+        P = fb.new_empty((B, L, Nq))
+        A = fb.new_empty((B, L, L))
+        call("smin_boundary_unit_fwd", stream(), ptr(fb), ptr(fw), ptr(fs), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr),
+             layout.N, B, L, Nq, D, ptr(Wq), ptr(bq), ptr(Wk), ptr(bk), ptr(qmask), ptr(lmask),
+             ptr(out), ptr(Qb), ptr(Kb), ptr(P), ptr(baq), ptr(bqv), ptr(A))
+        ctx.save_for_backward(fb, fw, fs, hbar, Wq, Wk, qmask, lmask, Qb, Kb, P, baq, bqv, A)
+        ctx.layout = layout
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fb, fw, fs, hbar, Wq, Wk, qmask, lmask, Qb, Kb, P, baq, bqv, A = ctx.saved_tensors
+        layout = ctx.layout
+        B, L, D = fb.shape
+        Nq = fw.shape[1]
+        dout = _c(dout)
+        WqT, WkT = Wq.t().contiguous(), Wk.t().contiguous()
+        dfb, dfw, dfs, dhbar = torch.empty_like(fb), torch.empty_like(fw), torch.empty_like(fs), torch.empty_like(hbar)
+        dWq, dbq, dWk, dbk = torch.empty_like(Wq), fb.new_empty((D,)), torch.empty_like(Wk), fb.new_empty((D,))
+        nbytes = 4 * (2 * B * L * L + 3 * B * L * D + B * L * Nq + B * Nq * D + 2 * 64 * (D * D + D)) + 4096
+        _, wp, wn = _ws(nbytes, fb.device)
+        call("smin_boundary_unit_bwd", stream(), ptr(dout), ptr(fb), ptr(fw), ptr(fs), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr),
+             layout.N, B, L, Nq, D, ptr(WqT), ptr(WkT), ptr(qmask), ptr(lmask), ptr(Qb), ptr(Kb), ptr(P), ptr(baq), ptr(bqv), ptr(A),
+             ptr(dfb), ptr(dfw), ptr(dfs), ptr(dhbar), ptr(dWq), ptr(dbq), ptr(dWk), ptr(dbk), wp, wn)
+        return dfb, dfw, dfs, dhbar, dWq, dbq, dWk, dbk, None, None, None
+
+
 class MomentUnitFn(Function):
     """MomentUnit.forward (reference models.py:288-303); Wcat = [conv_fb.W | conv_fc.W] (D, 2D)."""
 

@@ -9,8 +9,8 @@ so ``torch.manual_seed(s); SMIN(...)`` reproduces the reference's default initia
 Inside ``SMIN.forward`` the L x L map lives in the packed valid-cell layout (cells.py); the dense
 (B, L, L, ...) tensors of the reference appear only at the stand-alone sub-module seams
 (``ContentUnit.forward`` etc.), which convert at the boundary and accept arbitrary dense inputs.
-Per-cell work runs in HIP (functional.py); O(B*Nq) / O(B*L*L*D) glue (query projections, the L x L
-boundary self-attention) and the backbone stay plain torch library calls.
+Per-cell work and the whole boundary unit run in HIP (functional.py); the O(B*Nq*dl) word-side projections of the
+content unit and the backbone stay plain torch library calls.
 """
 import math
 
@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .cells import CellLayout
-from .functional import BoundaryReduceFn, ContentUnitFn, GateFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
+from .functional import BoundaryUnitFn, ContentUnitFn, GateFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
 
 
 def _rows(mask):
@@ -163,16 +163,9 @@ class BoundaryUnit(nn.Module):
         self.attn_layer = Attention(D)
 
     def forward_packed(self, f_b, f_w, f_s, hbar, query_mask, length_mask, layout):
-        lm = length_mask.float()
-        lcol = lm.unsqueeze(-1)
-        baq = self.attn_layer(f_b, f_w, f_w, query_mask) * lcol
-        bq = f_b * (baq + f_s.unsqueeze(1))
-        z = torch.bmm(bq, bq.transpose(1, 2)) / math.sqrt(self.D)
-        lrow = lm.unsqueeze(1)
-        A = torch.softmax((z * lrow).masked_fill(lrow == 0, -1e9), dim=-1) * lcol
-        f_bb = torch.bmm(A, f_b) * lcol
-        f_bm = BoundaryReduceFn.apply(A, hbar, layout)             # HIP: gated row reduction of the map
-        return f_bb + f_b + f_bm
+        at = self.attn_layer
+        return BoundaryUnitFn.apply(f_b, f_w, f_s, hbar, at.W_q.weight, at.W_q.bias, at.W_k.weight, at.W_k.bias,
+                                    _rows(query_mask), length_mask.float(), layout)
 
     def forward(self, f_b, f_w, f_s, f_m, query_mask, length_mask):
         B, L = f_m.shape[:2]
