@@ -120,13 +120,14 @@ def main():
         print("bench.py: --gpus N > 1 must be launched through torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks may share the one GPU of a test box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import models
     from vml_amd import distributed as dp, functional as Fn, loss_fn
     models.vml_amd._lib.load()
     models.vml_amd.set_gemm_mode(args.gemm)
-    dp.init(backend="nccl", device=dev)                           # nccl == RCCL on ROCm (xGMI inside the node)
+    dp.init(backend=os.environ.get("SMIN_DIST_BACKEND", "nccl"), device=dev)   # nccl == RCCL on ROCm (xGMI inside the node)
 
     cfg = WORKLOADS[args.workload]
     T, L, C, D, dl, layers, Din, Nq, Hh, B = cfg

@@ -147,6 +147,19 @@ int smin_score_map_bwd(void* stream, const float* dpm, const float* dpsea, const
                        const float* wm, const float* wb, const float* lmask,
                        float* dfm, float* dfb, float* dwm, float* dbm, float* dwb, float* dbb, void* ws, size_t ws_bytes);
 
+/* ---- Restated train-step loss (reference main.py:89-116 with reduction='none'):
+ *   loss = L_m + L_s + L_e + 0.5 L_a, scaled BCE, masked, per-sample mean then batch mean.
+ * pm/sm [B][L][L], ps/pe/pa/ss/se [B][L] fp32; ym/mm [B][L][L], ys/ye/ya/lm [B][L] as bytes (bool / uint8).
+ * loss [1]; part [B][6] scratch kept for backward.  Backward writes dpm [B][L][L], dps/dpe/dpa [B][L]. */
+int smin_loss_fwd(void* stream, const float* pm, const uint8_t* ym, const float* sm, const uint8_t* mm,
+                  const float* ps, const uint8_t* ys, const float* ss, const float* pe, const uint8_t* ye, const float* se,
+                  const float* pa, const uint8_t* ya, const uint8_t* lm, int B, int L, float* loss, float* part);
+int smin_loss_bwd(void* stream, const float* dloss, const float* part,
+                  const float* pm, const uint8_t* ym, const float* sm, const uint8_t* mm,
+                  const float* ps, const uint8_t* ys, const float* ss, const float* pe, const uint8_t* ye, const float* se,
+                  const float* pa, const uint8_t* ya, const uint8_t* lm, int B, int L,
+                  float* dpm, float* dps, float* dpe, float* dpa);
+
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);

@@ -283,3 +283,21 @@ def test_full_size_against_golden_bf16x3(dev, bf16x3, name):
         worst = max(worst, abs(got - norms[k]) / (norms[k] + 1e-12))
         assert abs(got - norms[k]) <= 5e-3 * norms[k] + 1e-7, (k, got, norms[k])
     print("bf16x3", name, "worst grad-norm deviation", worst)
+
+
+def test_fused_loss_matches_torch_restatement(dev):
+    """vml_amd.loss_fn on device (two fused kernels) against the torch restatement: value and the four score gradients."""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn, loss_fn_torch
+    cfg, sd, batch, out, _, loss_ref = H.split_tiny(H.load_npz("g2_r2_ragged"))
+    b = {k: v.to(dev) for k, v in batch.items()}
+    leaves = [out[k].to(dev).clone().requires_grad_(True) for k in ("pm", "ps", "pe", "pa")]
+    ref_leaves = [out[k].to(dev).clone().requires_grad_(True) for k in ("pm", "ps", "pe", "pa")]
+    args = lambda p: (p[0], b["ym"], b["sm"], b["moment_mask"], p[1], b["ys"], b["ss"], p[2], b["ye"], b["se"], p[3], b["ya"], b["length_mask"])
+    l1 = loss_fn(*args(leaves))
+    l0 = loss_fn_torch(*args(ref_leaves))
+    assert abs(l1.item() - l0.item()) < 1e-5 and abs(l1.item() - loss_ref) < 1e-5
+    (l1 * 1.7).backward()
+    (l0 * 1.7).backward()
+    for a, r in zip(leaves, ref_leaves):
+        assert (a.grad - r.grad).abs().max().item() <= 1e-5 * r.grad.abs().max().item() + 1e-9

@@ -33,6 +33,8 @@ SIGNATURES = {
     "smin_moment_unit_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz],
     "smin_score_map_fwd": [_vp] * 4 + [_i] * 4 + [_vp] * 7,
     "smin_score_map_bwd": [_vp] * 8 + [_i] * 4 + [_vp] * 3 + [_vp] * 6 + [_vp, _sz],
+    "smin_loss_fwd": [_vp] * 14 + [_i] * 2 + [_vp] * 2,
+    "smin_loss_bwd": [_vp] * 16 + [_i] * 2 + [_vp] * 4,
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
@@ -85,7 +87,7 @@ def ptr(t):
         raise SminHipError("the SMIN hot path runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
     if not t.is_contiguous():
         raise SminHipError("internal error: non-contiguous tensor handed to the C ABI")
-    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float64):
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float64, torch.bool):
         raise SminHipError(f"unsupported dtype {t.dtype}")
     return ctypes.c_void_p(t.data_ptr())
 

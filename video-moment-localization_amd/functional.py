@@ -279,6 +279,32 @@ class ScoreMapFn(Function):
         return dfm, dfb, dwm, dbm, dwb, dbb, None, None
 
 
+class LossFn(Function):
+    """Restated loss of the reference's train loop (main.py:89-116) as one forward and one backward kernel."""
+
+    @staticmethod
+    def forward(ctx, pm, ps, pe, pa, ym, sm, mm, ys, ss, ye, se, ya, lm):
+        pm, ps, pe, pa, sm, ss, se = (_c(x.float()) for x in (pm, ps, pe, pa, sm, ss, se))
+        ym, mm, ys, ye, ya, lm = (_c(x if x.dtype in (torch.bool, torch.uint8) else x != 0) for x in (ym, mm, ys, ye, ya, lm))
+        B, L = ps.shape
+        loss = pm.new_empty((1,))
+        part = pm.new_empty((B, 6))
+        call("smin_loss_fwd", stream(), ptr(pm), ptr(ym), ptr(sm), ptr(mm), ptr(ps), ptr(ys), ptr(ss), ptr(pe), ptr(ye), ptr(se),
+             ptr(pa), ptr(ya), ptr(lm), B, L, ptr(loss), ptr(part))
+        ctx.save_for_backward(pm, ps, pe, pa, ym, sm, mm, ys, ss, ye, se, ya, lm, part)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pm, ps, pe, pa, ym, sm, mm, ys, ss, ye, se, ya, lm, part = ctx.saved_tensors
+        B, L = ps.shape
+        dloss = _c(dloss.reshape(1).float())
+        dpm, dps, dpe, dpa = torch.empty_like(pm), torch.empty_like(ps), torch.empty_like(pe), torch.empty_like(pa)
+        call("smin_loss_bwd", stream(), ptr(dloss), ptr(part), ptr(pm), ptr(ym), ptr(sm), ptr(mm), ptr(ps), ptr(ys), ptr(ss),
+             ptr(pe), ptr(ye), ptr(se), ptr(pa), ptr(ya), ptr(lm), B, L, ptr(dpm), ptr(dps), ptr(dpe), ptr(dpa))
+        return (dpm, dps, dpe, dpa) + (None,) * 9
+
+
 def gemm_nt(a, b):
     """C = A @ B^T on the library's fp32 MFMA engine (tests / bench roofline probe)."""
     a, b = _c(a), _c(b)

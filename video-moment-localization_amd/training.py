@@ -20,10 +20,19 @@ def bce_loss(p, y, s, mask):
     return (loss.sum(dim=dims) / mk.sum(dim=dims)).mean()
 
 
-def loss_fn(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask):
-    """reference main.py:110-116: L_m + L_s + L_e + 0.5 L_a."""
+def loss_fn_torch(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask):
+    """reference main.py:110-116: L_m + L_s + L_e + 0.5 L_a, as plain torch ops (any device)."""
     return (bce_loss(pm, ym, sm, moment_mask) + bce_loss(ps, ys, ss, length_mask)
             + bce_loss(pe, ye, se, length_mask) + 0.5 * bce_loss(pa, ya, None, length_mask))
+
+
+def loss_fn(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask):
+    """reference main.py:110-116 (same argument order).  On a HIP device this is one fused forward and one fused
+    backward kernel (functional.LossFn) instead of ~40 element-wise launches; elsewhere the torch restatement."""
+    if pm.is_cuda:
+        from .functional import LossFn
+        return LossFn.apply(pm, ps, pe, pa, ym, sm, moment_mask, ys, ss, ye, se, ya, length_mask)
+    return loss_fn_torch(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask)
 
 
 def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
