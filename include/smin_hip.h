@@ -160,6 +160,11 @@ int smin_loss_bwd(void* stream, const float* dloss, const float* part,
                   const float* pa, const uint8_t* ya, const uint8_t* lm, int B, int L,
                   float* dpm, float* dps, float* dpe, float* dpa);
 
+/* ---- compute_ious (reference utils.py:10-31): counts [8] = number of samples with a hit for
+ * R@1 x IoU {0.1, 0.3, 0.5, 0.7} then R@5 x the same; ws [B][8] scratch; L*L*4 bytes of LDS per sample (L <= 196). */
+int smin_compute_ious(void* stream, const float* pm, const float* ps, const float* pe, const uint8_t* mm, const float* sm,
+                      int B, int L, float* counts, float* ws);
+
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);

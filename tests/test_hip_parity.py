@@ -301,3 +301,21 @@ def test_fused_loss_matches_torch_restatement(dev):
     (l0 * 1.7).backward()
     for a, r in zip(leaves, ref_leaves):
         assert (a.grad - r.grad).abs().max().item() <= 1e-5 * r.grad.abs().max().item() + 1e-9
+
+
+def test_compute_ious_on_device(dev):
+    """utils.py:10-31 metric: the one-kernel device version against the reference's own fixture and the torch restatement."""
+    import models
+    z = H.load_npz("g6_ious")
+    args = [torch.from_numpy(z[k]).to(dev) for k in ("pm", "ps", "pe", "mm", "sm")]
+    got = models.vml_amd.compute_ious(*args)
+    for k, v in zip(z["keys"], z["vals"]):
+        assert got[str(k)] == float(v), k
+    g = torch.Generator().manual_seed(11)
+    B, L = 9, 64
+    lm = torch.ones(B, L, dtype=torch.bool); lm[2, 40:] = False
+    mm = torch.triu(lm.unsqueeze(2) & lm.unsqueeze(1))
+    pm, ps, pe, sm = torch.rand(B, L, L, generator=g) * mm, torch.rand(B, L, generator=g), torch.rand(B, L, generator=g), torch.rand(B, L, L, generator=g) * mm
+    want = models.vml_amd.compute_ious(pm, ps, pe, mm, sm)                      # CPU tensors -> torch path
+    got = models.vml_amd.compute_ious(*(x.to(dev) for x in (pm, ps, pe, mm, sm)))
+    assert got == want

@@ -35,6 +35,7 @@ SIGNATURES = {
     "smin_score_map_bwd": [_vp] * 8 + [_i] * 4 + [_vp] * 3 + [_vp] * 6 + [_vp, _sz],
     "smin_loss_fwd": [_vp] * 14 + [_i] * 2 + [_vp] * 2,
     "smin_loss_bwd": [_vp] * 16 + [_i] * 2 + [_vp] * 4,
+    "smin_compute_ious": [_vp] * 6 + [_i] * 2 + [_vp] * 2,
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
