@@ -145,6 +145,7 @@ def test_full_size_against_golden(dev, name):
     (48, 24, 4, 128, 64, 1, 32, 20, 64, 3),      # r = 2 < C: empty clips and dropped frames
     (64, 32, 2, 64, 16, 2, 16, 3, 32, 2),
     (96, 32, 3, 128, 128, 3, 24, 32, 64, 1),     # B = 1 (the reference raises here), Nq = 32, dl = 128
+    (16, 16, 4, 64, 32, 2, 24, 6, 32, 3),        # r = 1: one frame per snippet (general proposal-map backward path)
 ])
 def test_against_oracle_random(dev, T, L, C, D, dl, layers, Din, Nq, Hh, B):
     from oracle import smin_oracle as O

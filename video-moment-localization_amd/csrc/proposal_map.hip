@@ -140,6 +140,100 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
     }
 }
 
+// Same result as proposal_map_bwd_events_kernel, organised for the machine: the clip equations of the start-snippet
+// rows are solved by one LANE per row (the version above has every thread of the workgroup repeat the whole scalar
+// search: ~25k integer instructions per workgroup), each lane leaving its events {cell, clip, +-1/cs, with-mean} in a
+// fixed slot range of an LDS list; the row that starts exactly at frame t (one event per window width) gets a list
+// of its own.  Then all threads stream the lists in (row, slot) order -- the order is fixed, so the sum is
+// bitwise reproducible -- with the dependent cellmap / mask lookups already resolved.
+constexpr int EV_SLOTS = 16;
+struct Ev { int nc; float sc; };                      // nc = (cell << 3) | (with_mean << 2 ... ) see pack below
+
+__global__ __launch_bounds__(128)
+void proposal_map_bwd_events2_kernel(const float* __restrict__ dfc, const float* __restrict__ dfm,
+                                     const int* __restrict__ cells, const int* __restrict__ cellmap,
+                                     int T, int L, int C, int D, float* __restrict__ E)
+{
+    extern __shared__ __attribute__((aligned(8))) unsigned char lds_raw[];
+    Ev* rowev = reinterpret_cast<Ev*>(lds_raw);                    // [L][EV_SLOTS]
+    Ev* zeroev = rowev + (size_t)L * EV_SLOTS;                      // [L]      events of the row with base == 0
+    int* cnt = reinterpret_cast<int*>(zeroev + L);                  // [L]
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int r = T / L;
+    const int* cmap = cellmap + (size_t)b * L * L;
+    const float invC = 1.0f / C;
+    const int imax = min(L - 1, t / r);
+    const int i0 = (t % r == 0 && t / r < L) ? t / r : -1;          // row whose window starts at frame t
+
+    auto lookup = [&](int i, int w) -> int {                        // cell id of (i, i+w-1) if present and unmasked
+        const int j = i + w - 1;
+        if (j >= L) return -1;
+        const int n = cmap[i * L + j];
+        if (n < 0 || cells[4 * (size_t)n + 3] == 0) return -1;
+        return n;
+    };
+    for (int i = tid; i < L; i += 128) {
+        int k = 0;
+        if (i <= imax && i != i0) {
+            const int base = t - i * r;
+            auto widths = [&](int c, int cs, float sign) {
+                int lo = (cs * C + r - 1) / r, hi = ((cs + 1) * C + r - 1) / r - 1;
+                if (cs == 1) lo = 1;
+                lo = max(lo, c / r + 1);
+                hi = min(hi, L - i);
+                for (int w = lo; w <= hi; ++w) {
+                    const int n = lookup(i, w);
+                    if (n >= 0 && k < EV_SLOTS) {
+                        const int with_m = (sign < 0.f && c + 1 == min(C, w * r)) ? 1 : 0;
+                        rowev[i * EV_SLOTS + k++] = Ev{(n << 4) | (with_m << 3) | c, sign / (float)cs};
+                    }
+                }
+            };
+            for (int c = 1; c < C; ++c) if (base % c == 0) widths(c, base / c, 1.0f);
+            for (int cc = 1; cc <= C; ++cc) if (base % cc == 0) widths(cc - 1, base / cc, -1.0f);
+        }
+        cnt[i] = k;
+    }
+    if (i0 >= 0)
+        for (int w = tid + 1; w <= L - i0; w += 128) {
+            const int n = lookup(i0, w);
+            zeroev[w - 1] = Ev{n >= 0 ? ((n << 4) | 8) : -1, 1.0f / (float)max(1, (w * r) / C)};
+        }
+    __syncthreads();
+
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f4zero();
+    auto apply = [&](Ev ev) {
+        if (ev.nc < 0) return;
+        const int n = ev.nc >> 4, c = ev.nc & 7;
+        const bool with_m = (ev.nc & 8) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = tid * 4 + 512 * k;
+            if (d < D) {
+                float4 g = f4zero();
+                if (dfc) g = ldg4(dfc + ((size_t)n * C + c) * D + d);
+                if (dfm && with_m) g = f4fma(ldg4(dfm + (size_t)n * D + d), invC, g);
+                acc[k] = f4fma(g, ev.sc, acc[k]);
+            }
+        }
+    };
+    for (int i = 0; i <= imax; ++i) {
+        if (i == i0) {
+            for (int w = 0; w < L - i0; ++w) apply(zeroev[w]);
+        } else {
+            const int k = cnt[i];
+            for (int q = 0; q < k; ++q) apply(rowev[i * EV_SLOTS + q]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = tid * 4 + 512 * k;
+        if (d < D) stg4(E + ((size_t)b * T + t) * D + d, acc[k]);
+    }
+}
+
 // df[b][t][d] = running sum of E over t (fp64 accumulator) + dfb[b][t / r][d] / r
 __global__ void proposal_map_bwd_scan_kernel(const float* __restrict__ E, const float* __restrict__ dfb, int B, int T, int L, int D,
                                              float* __restrict__ df)
@@ -193,7 +287,18 @@ extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float
     if (N > 0 && (dfc || dfm)) {
         SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * T * D);
         E = reinterpret_cast<float*>(ws);
-        hipLaunchKernelGGL(proposal_map_bwd_events_kernel, dim3(T, B), dim3(128), 0, st, dfc, dfm, cells, cellmap, T, L, C, D, E);
+        const int r = T / L;
+        const size_t lds = (size_t)L * EV_SLOTS * 8 + (size_t)L * 8 + (size_t)L * 4;
+        if (2 * C * cdiv(C, r) <= EV_SLOTS && C <= 8 && N < (1 << 27) && lds <= 150 * 1024) {
+            if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_map_bwd_events2_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(proposal_map_bwd_events2_kernel, dim3(T, B), dim3(128), lds, st, dfc, dfm, cells, cellmap, T, L, C, D, E);
+        } else {
+            hipLaunchKernelGGL(proposal_map_bwd_events_kernel, dim3(T, B), dim3(128), 0, st, dfc, dfm, cells, cellmap, T, L, C, D, E);
+        }
         SMIN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, dfb, B, T, L, D, df);
