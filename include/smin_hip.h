@@ -60,7 +60,9 @@ int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, cons
  *   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]          hbar [N][D]
  * backward: dfm [N][D], dfs [B][D] from dhbar (the sum of both consumers' gradients). */
 int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar);
-int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, const float* fs, const int32_t* row_ptr,
+int smin_gate_bwd(void* stream, const float* dhbar, const float* dhbar2 /* nullable: second consumer */,
+                  const float* dres /* nullable: gradient of the pass-through copy of fm, added to dfm */,
+                  const float* fm, const float* fs, const int32_t* row_ptr,
                   int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes);
 
 /* ---- ContentUnit.forward (models.py:242-276) incl. ContentAttention.forward (models.py:207-226).

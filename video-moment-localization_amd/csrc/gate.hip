@@ -1,6 +1,8 @@
 // Gated moment feature shared by the content and boundary units (reference models.py:191, 272-274):
 //   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]
-// computed once per layer (element-wise, HBM-bound) instead of inside every consumer.
+// computed once per layer (element-wise, HBM-bound) instead of inside every consumer.  The backward kernel also sums
+// the gradients of hbar's two consumers and of the residual copy of f_m, which autograd would otherwise add in
+// separate full-size passes.
 #include "common.h"
 #include "smin_hip.h"
 
@@ -21,7 +23,8 @@ __global__ void gate_fwd_kernel(const float* __restrict__ fm, const float* __res
 // dfm = dh * (g + fm*g*(1-g)*fs) ; partial[b][chunk][:] = sum over the chunk's cells of dh * fm^2 * g*(1-g)
 // grid (chunks, B), 128 threads, float4 columns.
 __global__ __launch_bounds__(128)
-void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ fm, const float* __restrict__ fs,
+void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dres,
+                     const float* __restrict__ fm, const float* __restrict__ fs,
                      const int* __restrict__ row_ptr, int L, int D, int cells_per_chunk, int max_chunks,
                      float* __restrict__ dfm, float* __restrict__ partial)
 {
@@ -34,7 +37,8 @@ void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ fm,
         const float4 s4 = ldg4(fs + (size_t)b * D + d);
         float4 acc = f4zero();
         for (int n = n_begin; n < n_end; ++n) {
-            const float4 ds = ldg4(dh + (size_t)n * D + d);
+            float4 ds = ldg4(dh + (size_t)n * D + d);
+            if (dh2) ds = f4add(ds, ldg4(dh2 + (size_t)n * D + d));       // second consumer of hbar (summed here, not by autograd)
             const float4 x = ldg4(fm + (size_t)n * D + d);
             float4 o;
 #define GATE1(F)                                                                  \
@@ -46,6 +50,7 @@ void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ fm,
             }
             GATE1(x) GATE1(y) GATE1(z) GATE1(w)
 #undef GATE1
+            if (dres) o = f4add(o, ldg4(dres + (size_t)n * D + d));         // gradient of the pass-through copy of f_m
             stg4(dfm + (size_t)n * D + d, o);
         }
         stg4(partial + ((size_t)b * max_chunks + chunk) * D + d, acc);
@@ -79,7 +84,8 @@ extern "C" int smin_gate_fwd(void* stream, const float* fm, const float* fs, con
     return 0;
 }
 
-extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, const float* fs, const int32_t* row_ptr,
+extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* dhbar2, const float* dres,
+                             const float* fm, const float* fs, const int32_t* row_ptr,
                              int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes)
 {
     (void)N;
@@ -88,7 +94,7 @@ extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* fm, 
     int cpc, mc; chunking(L, &cpc, &mc);
     SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * mc * D);
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dhbar, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dhbar, dhbar2, dres, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_partial_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, partial, row_ptr, L, D, cpc, mc, dfs);
     SMIN_LAUNCH_CHECK();

@@ -70,8 +70,11 @@ class ProposalMapFn(Function):
 
 
 class GateFn(Function):
-    """hbar = sigmoid(fm * fs) * fm -- the gated moment feature of models.py:191 and 272-274, computed once
-    per layer and shared by the content and boundary units."""
+    """hbar = sigmoid(fm * fs) * fm -- the gated moment feature of models.py:191 and 272-274, computed once per layer.
+
+    Returns (hbar for the content unit, the same hbar for the boundary unit, fm passed through for the moment unit's
+    residual).  The three outputs share storage pairwise; handing them out separately lets the one backward kernel
+    sum their gradients instead of autograd doing it in two extra full-size passes per layer."""
 
     @staticmethod
     def forward(ctx, fm, fs, layout):
@@ -81,17 +84,21 @@ class GateFn(Function):
         call("smin_gate_fwd", stream(), ptr(fm), ptr(fs), ptr(layout.cells), N, D, ptr(hbar))
         ctx.save_for_backward(fm, fs)
         ctx.layout = layout
-        return hbar
+        return hbar, hbar.view_as(hbar), fm.view_as(fm)
 
     @staticmethod
-    def backward(ctx, dhbar):
+    def backward(ctx, dh1, dh2, dres):
         fm, fs = ctx.saved_tensors
         layout = ctx.layout
         N, D = fm.shape
-        dhbar = _c(dhbar)
+        dh1, dh2, dres = _c(dh1), _c(dh2), _c(dres)
+        if dh1 is None:
+            dh1, dh2 = dh2, None
+        if dh1 is None:
+            dh1 = torch.zeros_like(fm)
         dfm, dfs = torch.empty_like(fm), torch.empty_like(fs)
         _, wp, wn = _ws(4 * layout.B * 64 * D + 4096, fm.device)
-        call("smin_gate_bwd", stream(), ptr(dhbar), ptr(fm), ptr(fs), ptr(layout.row_ptr), N, layout.B, layout.L, D,
+        call("smin_gate_bwd", stream(), ptr(dh1), ptr(dh2), ptr(dres), ptr(fm), ptr(fs), ptr(layout.row_ptr), N, layout.B, layout.L, D,
              ptr(dfm), ptr(dfs), wp, wn)
         return dfm, dfs, None
 

@@ -170,7 +170,7 @@ class BoundaryUnit(nn.Module):
     def forward(self, f_b, f_w, f_s, f_m, query_mask, length_mask):
         B, L = f_m.shape[:2]
         layout = CellLayout.all_cells(torch.ones(B, L, L, dtype=torch.bool, device=f_m.device))
-        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)
+        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)[0]
         return self.forward_packed(f_b, f_w, f_s, hbar, query_mask, length_mask, layout)
 
 
@@ -216,7 +216,7 @@ class ContentUnit(nn.Module):
 
     def forward(self, f_c, f_w, f_s, f_m, query_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
-        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)
+        hbar = GateFn.apply(layout.pack(f_m), f_s, layout)[0]
         out, _ = self.forward_packed(layout.pack(f_c), hbar, f_w, f_s, query_mask, layout)
         return layout.unpack(out)
 
@@ -255,10 +255,10 @@ class SMI(nn.Module):
     def forward_packed(self, fc, fm, f_b, f_w, f_s, query_mask, length_mask, layout, fcmean_in=None):
         """fcmean_in = mean_c fc marks the final layer of a stack (its content output is consumed only through the
         clip mean); the returned content tensor is then empty."""
-        hbar = GateFn.apply(fm, f_s, layout)                      # sigmoid(fm*fs)*fm, shared by both units
-        cu, cumean = self.content_unit.forward_packed(fc, hbar, f_w, f_s, query_mask, layout, fcmean_in)
-        bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, hbar, query_mask, length_mask, layout)
-        mu = self.moment_unit.forward_packed(cumean, fm, bu, layout)
+        hbar_c, hbar_b, fm_res = GateFn.apply(fm, f_s, layout)    # sigmoid(fm*fs)*fm for both units + fm for the residual
+        cu, cumean = self.content_unit.forward_packed(fc, hbar_c, f_w, f_s, query_mask, layout, fcmean_in)
+        bu = self.boundary_unit.forward_packed(f_b, f_w, f_s, hbar_b, query_mask, length_mask, layout)
+        mu = self.moment_unit.forward_packed(cumean, fm_res, bu, layout)
         return cu, mu, bu, cumean
 
     def forward(self, f_c, f_m, f_b, f_w, f_s, query_mask, length_mask, moment_mask):
