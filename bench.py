@@ -178,8 +178,8 @@ def main():
         achieved = flops / (avg_ms * 1e-3) / 1e12
         traffic = None
         tr_path = os.path.join(ROOT, "profiles", "pmc_moment_fwd.json")
-        if os.path.exists(tr_path):
-            try:
+        if os.path.exists(tr_path) and args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
+            try:                                            # PMC traffic was collected on exactly this workload
                 traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
