@@ -18,18 +18,26 @@ namespace smin {
 // ------------------------------------------------------------------ virtual matrices
 // Protocol:  Row row(int r) const                   (r in range, guaranteed by the caller)
 //            float4 at(const Row&, int c) const     (c % 4 == 0, c in range; must be branch-free)
+//            Key key(int r) / Row resolve(Key, r)   row() split in two: key() only issues the descriptor loads,
+//                                                   resolve() does the dependent pointer arithmetic later
 
 struct PlainMat {                       // row-major [rows][ld]
     const float* p; int ld;
     struct Row { const float* p; };
+    struct Key {};
     __device__ __forceinline__ Row row(int r) const { return Row{p + (size_t)r * ld}; }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
     __device__ __forceinline__ float4 at(const Row& r, int c) const { return ldg4(r.p + c); }
 };
 
 struct MaskedRowsMat {                  // row n of [N][ld] scaled by the cell mask m[n]
     const float* p; int ld; const int* cells;
     struct Row { const float* p; float m; };
+    struct Key { int m; };
     __device__ __forceinline__ Row row(int r) const { return Row{p + (size_t)r * ld, (float)cells[4 * (size_t)r + 3]}; }
+    __device__ __forceinline__ Key key(int r) const { return Key{cells[4 * (size_t)r + 3]}; }
+    __device__ __forceinline__ Row resolve(const Key& k, int r) const { return Row{p + (size_t)r * ld, (float)k.m}; }
     __device__ __forceinline__ float4 at(const Row& r, int c) const { return f4scale(ldg4(r.p + c), r.m); }
 };
 
@@ -37,10 +45,12 @@ struct MaskedRowsMat {                  // row n of [N][ld] scaled by the cell m
 struct PairMeanMat {
     const float* fb; const float* fcmean; const int* cells; int L, D;
     struct Row { const float* bi; const float* bj; const float* cm; };
-    __device__ __forceinline__ Row row(int r) const {
-        const Cell c = load_cell(cells, r);
-        const float* base = fb + (size_t)c.b * L * D;
-        return Row{base + (size_t)c.i * D, base + (size_t)c.j * D, fcmean + (size_t)r * D};
+    struct Key { int4 c; };
+    __device__ __forceinline__ Row row(int r) const { return resolve(key(r), r); }
+    __device__ __forceinline__ Key key(int r) const { return Key{*reinterpret_cast<const int4*>(cells + 4 * (size_t)r)}; }
+    __device__ __forceinline__ Row resolve(const Key& k, int r) const {
+        const float* base = fb + (size_t)k.c.x * L * D;
+        return Row{base + (size_t)k.c.y * D, base + (size_t)k.c.z * D, fcmean + (size_t)r * D};
     }
     __device__ __forceinline__ float4 at(const Row& r, int c) const {
         const bool first = c < D;
@@ -56,9 +66,11 @@ template <bool MASK, bool HAS_DFC>
 struct DoutEffMat {
     const float* dfc; const float* dmean; const int* cells; int C, D; float invC;
     struct Row { const float* a; const float* b; float m; };
-    __device__ __forceinline__ Row row(int r) const {
-        const int n = r / C;
-        return Row{HAS_DFC ? dfc + (size_t)r * D : nullptr, dmean + (size_t)n * D, MASK ? (float)cells[4 * (size_t)n + 3] : 1.0f};
+    struct Key { int m; };
+    __device__ __forceinline__ Row row(int r) const { return resolve(key(r), r); }
+    __device__ __forceinline__ Key key(int r) const { return Key{MASK ? cells[4 * (size_t)(r / C) + 3] : 1}; }
+    __device__ __forceinline__ Row resolve(const Key& k, int r) const {
+        return Row{HAS_DFC ? dfc + (size_t)r * D : nullptr, dmean + (size_t)(r / C) * D, (float)k.m};
     }
     __device__ __forceinline__ float4 at(const Row& r, int c) const {
         float4 v = f4scale(ldg4(r.b + c), invC);
@@ -122,7 +134,10 @@ __device__ __forceinline__ void gemm_nt_body(float* smem, const AM& am, const BM
     float* As = smem;
     float* Bs = smem + 2 * BM * LDT;
     const int tile_rows = MINI ? 32 : BM;
-    const int t = threadIdx.x, lr = t / KQ, kq = (t % KQ) * 4;
+    // thread -> (row, 16-byte chunk) of a staging pass: the 8 lanes that one ds_write_b128 group serves write rows R and
+    // R+4 (bank offsets 0 and 16 mod 32); with consecutive rows (20 dwords apart) 4 of the 16 banks would collide.
+    const int t = threadIdx.x, u = (t & 63) >> 2, kq = (t & 3) * 4;
+    const int lr = 16 * (t >> 6) + ((u >> 1) & 3) + 8 * (u >> 3) + 4 * (u & 1);
 
     // out-of-range rows are clamped: they only feed accumulator rows/columns that are never stored
     typename AM::Row arow[NP];
@@ -463,16 +478,25 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
     // is computed; the virtual-matrix rows change every tile here, so their lookups are part of the prefetch.
     struct Stage { float4 a[NP], b[NP]; };
     const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
+    // The rows of a virtual matrix change with every tile here, and their descriptors (cell lookups) are loads the
+    // operand loads depend on.  key() issues those lookups one call ahead; resolve() turns them into pointers only
+    // when the operand loads of that tile are issued, so no wave ever waits on a lookup it has just requested.
+    typename AM::Key ka[NP];
+    typename BM_::Key kb[NP];
+    auto row_of = [&](int kt, int p) { return min(m_begin + min(kt, max(nk - 1, 0)) * BK + lk + 8 * p, Mrows - 1); };
+    auto k_load = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { ka[p] = am.key(row_of(kt, p)); kb[p] = bm.key(row_of(kt, p)); }
+    };
     auto g_load = [&](Stage& st, int kt) {
         const int m0 = m_begin + min(kt, max(nk - 1, 0)) * BK;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int m = m0 + lk + 8 * p;
-            const bool ok = m < m_end;
-            const int mc = min(m, Mrows - 1);
-            st.a[p] = f4sel(ok, am.at(am.row(mc), ia));
-            st.b[p] = f4sel(ok, bm.at(bm.row(mc), jb));
+            const bool ok = m0 + lk + 8 * p < m_end;
+            st.a[p] = f4sel(ok, am.at(am.resolve(ka[p], row_of(kt, p)), ia));
+            st.b[p] = f4sel(ok, bm.at(bm.resolve(kb[p], row_of(kt, p)), jb));
         }
+        k_load(kt + 1);                                            // lookups for the next call (tiles are requested in order)
     };
     auto s_store = [&](const Stage& st, int buf) {
 #pragma unroll
@@ -503,6 +527,7 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
 
     Stage s0, s1;
     if (nk > 0) {
+        k_load(0);
         g_load(s0, 0);
         s_store(s0, 0);
         g_load(s0, 1);
