@@ -320,3 +320,33 @@ def test_compute_ious_on_device(dev):
     want = models.vml_amd.compute_ious(pm, ps, pe, mm, sm)                      # CPU tensors -> torch path
     got = models.vml_amd.compute_ious(*(x.to(dev) for x in (pm, ps, pe, mm, sm)))
     assert got == want
+
+
+# ---------------------------------------------------------------- C ABI entry points not reached through the module mirror
+def test_c_abi_layout_helpers_and_boundary_reduce(dev):
+    import models
+    from vml_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(21)
+    B, L, D = 3, 12, 32
+    mm = (torch.rand(B, L, L, generator=g) > 0.5).to(dev)
+    lay = models.vml_amd.CellLayout.from_mask(mm)
+    dense = torch.randn(B, L, L, D, generator=g).to(dev)
+    packed = torch.empty(lay.N, D, device=dev)
+    call("smin_pack_cells", stream(), ptr(dense), ptr(lay.cells), lay.N, L, D, ptr(packed))
+    assert torch.equal(packed, lay.pack(dense))
+    back = torch.zeros_like(dense)
+    call("smin_unpack_cells", stream(), ptr(packed), ptr(lay.cells), lay.N, L, D, ptr(back))
+    assert torch.equal(back, dense * mm.unsqueeze(-1))
+    # fbm[b,i] = sum_j Ab[b,i,j] hbar[(b,i,j)]  and its two gradients
+    Ab = torch.randn(B, L, L, generator=g).to(dev)
+    hbar = torch.randn(lay.N, D, generator=g).to(dev)
+    fbm = torch.empty(B, L, D, device=dev)
+    call("smin_boundary_reduce_fwd", stream(), ptr(Ab), ptr(hbar), ptr(lay.cells), ptr(lay.row_ptr), lay.N, B, L, D, ptr(fbm))
+    hd = lay.unpack(hbar)
+    ref = (Ab.unsqueeze(-1) * hd).sum(dim=2)
+    assert (fbm - ref).abs().max().item() < 1e-5
+    dy = torch.randn(B, L, D, generator=g).to(dev)
+    dAb, dh = torch.empty_like(Ab), torch.empty_like(hbar)
+    call("smin_boundary_reduce_bwd", stream(), ptr(dy), ptr(Ab), ptr(hbar), ptr(lay.cells), ptr(lay.row_ptr), lay.N, B, L, D, ptr(dAb), ptr(dh))
+    assert (dAb - (dy.unsqueeze(2) * hd).sum(-1) * mm).abs().max().item() < 1e-4
+    assert (dh - lay.pack(Ab.unsqueeze(-1) * dy.unsqueeze(2))).abs().max().item() < 1e-5

@@ -158,33 +158,6 @@ class ContentUnitFn(Function):
         return dfc, dhbar, dWch, dbch, dMq, duq, dwhat, dshat, None, dWc, dbc, None, None
 
 
-class BoundaryReduceFn(Function):
-    """The map-sized term of BoundaryUnit.forward (reference models.py:190-194): fbm = sum_j A_b[i,j] hbar[(i,j)]."""
-
-    @staticmethod
-    def forward(ctx, Ab, hbar, layout):
-        Ab, hbar = _c(Ab), _c(hbar)
-        B, L, _ = Ab.shape
-        D = hbar.shape[1]
-        fbm = hbar.new_empty((B, L, D))
-        call("smin_boundary_reduce_fwd", stream(), ptr(Ab), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr), layout.N, B, L, D, ptr(fbm))
-        ctx.save_for_backward(Ab, hbar)
-        ctx.layout = layout
-        return fbm
-
-    @staticmethod
-    def backward(ctx, dfbm):
-        Ab, hbar = ctx.saved_tensors
-        layout = ctx.layout
-        B, L, _ = Ab.shape
-        D = hbar.shape[1]
-        dfbm = _c(dfbm)
-        dAb, dhbar = torch.empty_like(Ab), torch.empty_like(hbar)
-        call("smin_boundary_reduce_bwd", stream(), ptr(dfbm), ptr(Ab), ptr(hbar), ptr(layout.cells), ptr(layout.row_ptr),
-             layout.N, B, L, D, ptr(dAb), ptr(dhbar))
-        return dAb, dhbar, None
-
-
 class BoundaryUnitFn(Function):
     """BoundaryUnit.forward with its word attention (reference models.py:137-196), all in HIP."""
 
