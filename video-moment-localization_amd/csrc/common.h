@@ -18,12 +18,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// chunking of each sample's cell range over workgroups: <= 64 chunks per sample, >= 32 cells each
+// chunking of each sample's cell range over workgroups.
+// coarse (attention kernels: every workgroup first stages its sample's K/V tiles in LDS): <= 64 chunks, >= 64 cells each
 static inline void chunking(int L, int* cells_per_chunk, int* max_chunks)
 {
     const int max_cells = L * L;
     int cpc = cdiv(max_cells, 64);
-    if (cpc < 32) cpc = 32;
+    if (cpc < 64) cpc = 64;
+    *cells_per_chunk = cpc;
+    *max_chunks = cdiv(max_cells, cpc);
+}
+// fine (streaming element-wise kernels with a per-sample reduction): <= 512 chunks, >= 32 cells each
+static inline void chunking_fine(int L, int* cells_per_chunk, int* max_chunks)
+{
+    const int max_cells = L * L;
+    int mc = cdiv(max_cells, 32);
+    if (mc > 512) mc = 512;
+    if (mc < 1) mc = 1;
+    const int cpc = cdiv(max_cells, mc);
     *cells_per_chunk = cpc;
     *max_chunks = cdiv(max_cells, cpc);
 }

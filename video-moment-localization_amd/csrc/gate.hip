@@ -91,7 +91,7 @@ extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* dhba
     (void)N;
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
-    int cpc, mc; chunking(L, &cpc, &mc);
+    int cpc, mc; chunking_fine(L, &cpc, &mc);
     SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * mc * D);
     float* partial = reinterpret_cast<float*>(ws);
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dhbar, dhbar2, dres, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);

@@ -204,28 +204,32 @@ void proposal_map_bwd_events2_kernel(const float* __restrict__ dfc, const float*
     float4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = f4zero();
-    auto apply = [&](Ev ev) {
-        if (ev.nc < 0) return;
-        const int n = ev.nc >> 4, c = ev.nc & 7;
-        const bool with_m = (ev.nc & 8) != 0;
+    // four events per step: their row loads are independent, so eight HBM requests are in flight per lane
+    auto apply4 = [&](const Ev* ev, int cnt4) {
+        float4 gc[4], gm[4];
+        float sc[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = tid * 4 + 512 * k;
-            if (d < D) {
-                float4 g = f4zero();
-                if (dfc) g = ldg4(dfc + ((size_t)n * C + c) * D + d);
-                if (dfm && with_m) g = f4fma(ldg4(dfm + (size_t)n * D + d), invC, g);
-                acc[k] = f4fma(g, ev.sc, acc[k]);
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k];
+        for (int kd = 0; kd < 4; ++kd) {
+            const int d = tid * 4 + 512 * kd;
+            if (d >= D) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const Ev e = ev[min(u, cnt4 - 1)];
+                const bool ok = u < cnt4 && e.nc >= 0;
+                const int n = ok ? e.nc >> 4 : 0, c = e.nc & 7;
+                sc[u] = ok ? e.sc : 0.f;
+                gc[u] = (dfc && ok) ? ldg4(dfc + ((size_t)n * C + c) * D + d) : f4zero();
+                gm[u] = (dfm && ok && (e.nc & 8)) ? ldg4(dfm + (size_t)n * D + d) : f4zero();
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[kd] = f4fma(f4fma(gm[u], invC, gc[u]), sc[u], acc[kd]);
         }
     };
     for (int i = 0; i <= imax; ++i) {
-        if (i == i0) {
-            for (int w = 0; w < L - i0; ++w) apply(zeroev[w]);
-        } else {
-            const int k = cnt[i];
-            for (int q = 0; q < k; ++q) apply(rowev[i * EV_SLOTS + q]);
-        }
+        const Ev* list = i == i0 ? zeroev : rowev + (size_t)i * EV_SLOTS;
+        const int k = i == i0 ? L - i0 : cnt[i];
+        for (int q = 0; q < k; q += 4) apply4(list + q, min(4, k - q));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

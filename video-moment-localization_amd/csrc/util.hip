@@ -76,7 +76,7 @@ extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int N
     (void)Nq;
     const size_t M = (size_t)N * C;
     // content unit bwd: 2 x [M][dl] + TN slabs (<= 64 splits) + attention slabs + gate partials
-    size_t content = 3 * M * dl + 2 * M * 32 + 2 * (size_t)192 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 64 * D;
+    size_t content = 3 * M * dl + 2 * M * 32 + 2 * (size_t)192 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 512 * D;
     // moment unit bwd: dX1 [N][D] + slabs [64][D][2D] + bias slabs
     size_t moment = (size_t)N * D + (size_t)192 * ((size_t)D * 2 * D + D);
     // boundary / score: per-row partials

@@ -97,7 +97,7 @@ class GateFn(Function):
         if dh1 is None:
             dh1 = torch.zeros_like(fm)
         dfm, dfs = torch.empty_like(fm), torch.empty_like(fs)
-        _, wp, wn = _ws(4 * layout.B * 64 * D + 4096, fm.device)
+        _, wp, wn = _ws(4 * layout.B * 512 * D + 4096, fm.device)
         call("smin_gate_bwd", stream(), ptr(dh1), ptr(dh2), ptr(dres), ptr(fm), ptr(fs), ptr(layout.row_ptr), N, layout.B, layout.L, D,
              ptr(dfm), ptr(dfs), wp, wn)
         return dfm, dfs, None
