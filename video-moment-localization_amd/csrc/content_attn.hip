@@ -92,6 +92,18 @@ struct RowGeom {
     float m;            // cell mask
     bool nbok[4];       // neighbour clip c ^ o exists
 };
+// geometry without the mask (pure arithmetic); the caller supplies m once its load has landed
+__device__ __forceinline__ RowGeom row_geom_nomask(int n0, int n_end, int C, int lane) {
+    const int j = lane & 31, cell = n0 + (j >> 2), c = j & 3;
+    RowGeom g;
+    g.ok = cell < n_end && c < C;
+    const int cc = g.ok ? cell : n0;
+    g.row = cc * C + (g.ok ? c : 0);
+    g.m = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) g.nbok[o] = (c ^ o) < C;
+    return g;
+}
 __device__ __forceinline__ RowGeom row_geom(const int* cells, int n0, int n_end, int C, int lane) {
     const int j = lane & 31, cell = n0 + (j >> 2), c = j & 3;
     RowGeom g;
@@ -113,6 +125,20 @@ __device__ __forceinline__ void load_rows(float (&v)[DL / 8][4], const float* sr
         const float4 x = ldg4(src + (size_t)g.row * dl + min(d, dl - 4));
         const bool ok = g.ok && d < dl;
         v[kg][0] = ok ? x.x : 0.f; v[kg][1] = ok ? x.y : 0.f; v[kg][2] = ok ? x.z : 0.f; v[kg][3] = ok ? x.w : 0.f;
+    }
+}
+// the same in two halves: request the rows (raw, clamped addresses) early, mask them when they are first used
+template <int DL>
+__device__ __forceinline__ void request_rows(float4 (&raw)[DL / 8], const float* src, const RowGeom& g, int dl, int h) {
+#pragma unroll
+    for (int kg = 0; kg < DL / 8; ++kg) raw[kg] = ldg4(src + (size_t)g.row * dl + min(8 * kg + 4 * h, dl - 4));
+}
+template <int DL>
+__device__ __forceinline__ void accept_rows(float (&v)[DL / 8][4], const float4 (&raw)[DL / 8], const RowGeom& g, int dl, int h) {
+#pragma unroll
+    for (int kg = 0; kg < DL / 8; ++kg) {
+        const bool ok = g.ok && 8 * kg + 4 * h < dl;
+        v[kg][0] = ok ? raw[kg].x : 0.f; v[kg][1] = ok ? raw[kg].y : 0.f; v[kg][2] = ok ? raw[kg].z : 0.f; v[kg][3] = ok ? raw[kg].w : 0.f;
     }
 }
 template <int DL>
@@ -289,27 +315,40 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
     const int n_begin = s0 + chunk * cells_per_chunk;
     if (n_begin >= s1) return;
     const int n_end = min(s1, n_begin + cells_per_chunk);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
     AttnLds<DL> s(smem_dyn, true);
     stage_sample<DL>(s, true, Mq, uq, what, shat, qmask, b, dl, Nq);
     __syncthreads();
 
+    // one wave per SIMD: nothing but the wave's own instruction stream hides HBM latency, so the chat rows of the next
+    // tile are requested while this tile's tail runs, its mask at the top of this tile (a late scalar-ish load would
+    // have to drain every store in flight), and the gradient rows a phase before they are consumed
+    float4 chn[KG];
+    RowGeom gn = row_geom(cells, min(n_begin + 8 * wave, n_end - 1), n_end, C, lane);
+    if (n_begin + 8 * wave < n_end) request_rows<DL>(chn, chat, gn, dl, h);
     for (int n0 = n_begin + 8 * wave; n0 < n_end; n0 += 32) {
-        const RowGeom g = row_geom(cells, n0, n_end, C, lane);
+        const RowGeom g = gn;
+        // (unconditional: past the last tile the request is clamped onto the chunk's last cell and never accepted)
+        gn = row_geom_nomask(min(n0 + 32, n_end - 1), n_end, C, lane);
+        const int mn = cells[4 * (size_t)(gn.row / C) + 3];
         float ch[KG][4], P[16], Ao[4];
-        load_rows<DL>(ch, chat, g, dl, h);
+        accept_rows<DL>(ch, chn, g, dl, h);
+        float4 gq[KG];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+            gq[kg] = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(8 * kg + 4 * h, dl - 4));
         scores_softmax<DL>(P, ch, s, Nq, scale, lane);
         __builtin_amdgcn_sched_barrier(0);
         clip_attention<DL>(Ao, ch, P, s, g, Nq, scale, lane);
 
-        // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}   (g streamed, never held whole)
+        // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
         float dch[KG][4];
         float dAo[4] = {0.f, 0.f, 0.f, 0.f};
         const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int d = 8 * kg + 4 * h;
-            const float4 g4 = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(d, dl - 4));
+            const float4 g4 = gq[kg];
             const bool ok = g.ok && d < dl;
             const float gv[4] = {ok ? g4.x : 0.f, ok ? g4.y : 0.f, ok ? g4.z : 0.f, ok ? g4.w : 0.f};
 #pragma unroll
@@ -372,6 +411,8 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        gn.m = gn.ok ? (float)mn : 0.f;
+        request_rows<DL>(chn, chat, gn, dl, h);
         // P = softmax(S), S = (raw + u) * scale * qmask
         float pd = 0.f;
 #pragma unroll

@@ -49,6 +49,13 @@ class QueryEncoder(nn.Module):
         self.max_query_length, self.lstm_hidden_size = max_query_length, lstm_hidden_size
         self.lstm = nn.LSTM(input_size=300, hidden_size=lstm_hidden_size, num_layers=2, bidirectional=True, batch_first=True)
 
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device)
+            self._side = st
+        return st
+
     def forward(self, query_features, query_mask):
         """Same result as the reference's pack_padded_sequence / pad_packed_sequence round trip, but on padded
         tensors with the lengths kept on the device: the reference copies them to the host here
@@ -63,15 +70,32 @@ class QueryEncoder(nn.Module):
         rev = (length.unsqueeze(1) - 1 - t).clamp(min=0).unsqueeze(-1)                     # (B, Nq, 1)
         h0 = query_features.new_zeros(1, B, H)
         x = query_features
+
+        def run(layer, sfx, x):
+            w = [getattr(self.lstm, f"{n}_l{layer}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            xin = x if not sfx else torch.gather(x, 1, rev.expand(-1, -1, x.shape[-1])) * valid
+            y = torch._VF.lstm(xin, (h0, h0), w, True, 1, 0.0, self.training, False, True)[0]
+            if sfx:
+                y = torch.gather(y, 1, rev.expand(-1, -1, H))
+            return y * valid
+
+        # The two directions of a layer are independent chains of Nq tiny, latency-bound kernels: on the GPU they run
+        # on two HIP streams side by side (autograd replays each chain's backward on the stream of its forward).
+        side = self._side_stream(x.device) if x.is_cuda else None
         for layer in range(2):
-            outs = []
-            for sfx in ("", "_reverse"):
-                w = [getattr(self.lstm, f"{n}_l{layer}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
-                xin = x if not sfx else torch.gather(x, 1, rev.expand(-1, -1, x.shape[-1])) * valid
-                y = torch._VF.lstm(xin, (h0, h0), w, True, 1, 0.0, self.training, False, True)[0]
-                if sfx:
-                    y = torch.gather(y, 1, rev.expand(-1, -1, H))
-                outs.append(y * valid)
+            if side is None:
+                outs = [run(layer, "", x), run(layer, "_reverse", x)]
+            else:
+                cur = torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    y_rev = run(layer, "_reverse", x)
+                y_fwd = run(layer, "", x)
+                cur.wait_stream(side)
+                for tns in (x, rev, valid, h0):
+                    tns.record_stream(side)
+                y_rev.record_stream(cur)
+                outs = [y_fwd, y_rev]
             x = torch.cat(outs, dim=2)
         fw = x
         if Nq < self.max_query_length:
