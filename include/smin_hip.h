@@ -51,10 +51,18 @@ size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int Nq);
  * fb = AvgPool1d(T/L) over time.  f [B][T][D]; fc [N][C][D]; fm [N][D]; fb [B][L][D]. */
 int smin_proposal_map_fwd(void* stream, const float* f, const int32_t* cells, int N, int B, int T, int L, int C, int D,
                           float* fc, float* fm, float* fb, void* ws, size_t ws_bytes /* >= 8*B*(T+1)*D */);
-/* df [B][T][D] = d/df of the three outputs (any of dfc/dfm/dfb may be NULL = zero).  ws_bytes >= 4*B*T*D. */
+/* (any of fc/fm/fb may be NULL = not wanted) */
+/* The clip-boundary table of a geometry (T, L, C): which clip of which (i, j) starts / ends at each frame -- the
+ * sparsity pattern of the reference's cached content matrix (models.py:88-98, 110).  Build once per geometry: call
+ * with table == NULL to get counts [T]; form the exclusive prefix offsets [T+1]; call with counts == NULL to fill
+ * table (8 bytes per entry, offsets[T] entries). */
+int smin_clip_event_table(void* stream, int T, int L, int C, int32_t* counts, const int32_t* offsets, void* table);
+/* df [B][T][D] = d/df of the three outputs (any of dfc/dfm/dfb may be NULL = zero).  ws_bytes >= 4*B*T*D.
+ * ev_offsets / ev_table: the geometry's clip-boundary table (NULL, NULL = derive the boundaries in-kernel, slower). */
 int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, const float* dfb,
                           const int32_t* cells, const int32_t* row_ptr, const int32_t* cellmap,
-                          int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes);
+                          int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes,
+                          const int32_t* ev_offsets, const void* ev_table);
 
 /* ---- Gated moment feature shared by ContentUnit (models.py:272-274) and BoundaryUnit (models.py:191):
  *   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]          hbar [N][D]
@@ -166,6 +174,48 @@ int smin_loss_bwd(void* stream, const float* dloss, const float* part,
  * R@1 x IoU {0.1, 0.3, 0.5, 0.7} then R@5 x the same; ws [B][8] scratch; L*L*4 bytes of LDS per sample (L <= 196). */
 int smin_compute_ious(void* stream, const float* pm, const float* ps, const float* pe, const uint8_t* mm, const float* sm,
                       int B, int L, float* counts, float* ws);
+
+/* ---- content stream (reference models.py:242-276 + 115-119, re-associated): the content unit's output
+ *   f_c' = m*(cc Wc^T + bc) + f_c + hbar   (models.py:269-276)
+ * is consumed only by the next unit's linear_c_hat (models.py:247) and, through mean_c, by the moment unit
+ * (models.py:295).  Both are linear, so the (N*C) x D tensor f_c is never formed: with g = f Wch^T,
+ *   chat_k = window_mean(g_k) + sum_{l<k} cc_l (Wch_k Wc_l)^T + (sum_{l<k} hbar_l) Wch_k^T + const
+ *   mean_c f_c^k = mean_c f_c^{k-1} + (mean_c cc_k) Wc_k^T + bc_k + hbar_k
+ * and every contraction over N*C rows has K, N <= dl.  The entry points below are the pieces; the Python host
+ * (modules.py: SMIN.forward) composes them under autograd.  Requires a mask-driven cell list (m == 1 everywhere). */
+
+/* out[s][n*C + c][:] = m * (mean over clip c of cell n of g[b][t][s*W:(s+1)*W] + bias[s*W:(s+1)*W])
+ * g [B][T][nseg*W] (nseg <= 8: one segment per layer), out [nseg][N*C][W]; ws >= 8*B*(T+1)*nseg*W bytes. */
+int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias, const int32_t* cells, int N, int B, int T, int L, int C,
+                               int W, int nseg, float* out, void* ws, size_t ws_bytes);
+/* dout: HOST array of nseg device pointers, dout[s] [N*C][W] -> dg [B][T][nseg*W]; ws >= 4*B*T*nseg*W bytes. */
+int smin_clip_window_means_bwd(void* stream, const float* const* dout, const int32_t* cells, const int32_t* row_ptr,
+                               const int32_t* cellmap, int N, int B, int T, int L, int C, int W, int nseg, float* dg,
+                               void* ws, size_t ws_bytes, const int32_t* ev_offsets, const void* ev_table);
+
+/* attention core of the content unit alone (models.py:252-267): chat [N*C][dl] -> cc [N*C][dl] and/or ccmean [N][dl]
+ * (either output may be NULL). */
+int smin_content_attn_fwd(void* stream, const float* chat, const int32_t* cells, const int32_t* row_ptr,
+                          int N, int B, int L, int C, int dl, int Nq,
+                          const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                          float* cc, float* ccmean);
+size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl);
+/* dcc [N*C][dl] and/or dccmean [N][dl] (one may be NULL) -> dchat [N*C][dl], dMq, duq, dwhat, dshat. */
+int smin_content_attn_bwd(void* stream, const float* dcc, const float* dccmean, const float* chat,
+                          const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int C, int dl, int Nq,
+                          const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                          float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, void* ws, size_t ws_bytes);
+
+/* y[r][:] = x[r][:] W^T + bias + add_rows[r][:] + add_cells[r / C][:]    x [R][K], W [O][K], y [R][O];
+ * bias, add_rows, add_cells may be NULL.  Backward: dx = dy W (WT = W^T [K][O]; dx may be NULL), dW = dy^T x,
+ * dbias = colsum(dy) (may be NULL); the gradient of add_rows is dy itself, of add_cells smin_group_sum(dy). */
+int smin_linear_rows_fwd(void* stream, const float* x, const float* W, const float* bias, const float* add_rows,
+                         const float* add_cells, int C, int R, int O, int K, float* y);
+size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int K);
+int smin_linear_rows_bwd(void* stream, const float* dy, const float* x, const float* WT, int R, int O, int K,
+                         float* dx, float* dW, float* dbias, void* ws, size_t ws_bytes);
+/* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
+int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);

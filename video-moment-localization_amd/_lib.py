@@ -20,7 +20,8 @@ SIGNATURES = {
     "smin_get_gemm_mode": [],
     "smin_workspace_bytes": [_i] * 6,
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
-    "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz],
+    "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp, _vp],
+    "smin_clip_event_table": [_vp] + [_i] * 3 + [_vp] * 3,
     "smin_gate_fwd": [_vp] * 4 + [_i] * 2 + [_vp],
     "smin_gate_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 2 + [_vp, _sz],
     "smin_content_unit_fwd": [_vp] * 5 + [_i] * 7 + [_vp] * 9 + [_vp, _i] + [_vp] * 4,
@@ -39,8 +40,18 @@ SIGNATURES = {
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
+    "smin_clip_window_means_fwd": [_vp] * 4 + [_i] * 7 + [_vp, _vp, _sz],
+    "smin_clip_window_means_bwd": [_vp] * 5 + [_i] * 7 + [_vp, _vp, _sz, _vp, _vp],
+    "smin_content_attn_fwd": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
+    "smin_content_attn_bwd_workspace_bytes": [_i] * 4,
+    "smin_content_attn_bwd": [_vp] * 6 + [_i] * 6 + [_vp] * 10 + [_vp, _sz],
+    "smin_linear_rows_fwd": [_vp] * 6 + [_i] * 4 + [_vp],
+    "smin_linear_rows_bwd_workspace_bytes": [_i] * 3,
+    "smin_linear_rows_bwd": [_vp] * 4 + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
+    "smin_group_sum": [_vp, _vp, _i, _i, _i, _vp],
 }
-_RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz}
+_RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
+            "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz}
 
 _lib = None
 _ws = {}
@@ -98,8 +109,9 @@ def stream():
 
 
 def workspace(nbytes, device):
-    """Persistent per-device scratch buffer, grown on demand (calls are stream-ordered)."""
-    key = (device.type, device.index)
+    """Persistent scratch buffer per (device, stream), grown on demand: calls on one stream are stream-ordered, and
+    units running side by side on two streams never share scratch."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

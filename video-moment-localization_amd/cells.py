@@ -8,10 +8,11 @@ import torch
 
 
 class CellLayout:
-    __slots__ = ("cells", "row_ptr", "cellmap", "N", "B", "L", "bidx", "iidx", "jidx")
+    __slots__ = ("cells", "row_ptr", "cellmap", "N", "B", "L", "bidx", "iidx", "jidx", "all_valid")
 
-    def __init__(self, cells, row_ptr, cellmap, B, L, idx):
+    def __init__(self, cells, row_ptr, cellmap, B, L, idx, all_valid=False):
         self.cells, self.row_ptr, self.cellmap = cells, row_ptr, cellmap
+        self.all_valid = all_valid                                # mask-driven list: every listed cell has m == 1
         self.N, self.B, self.L = int(cells.shape[0]), B, L
         self.bidx, self.iidx, self.jidx = idx[:, 0], idx[:, 1], idx[:, 2]
 
@@ -30,7 +31,7 @@ class CellLayout:
         row_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         cellmap = torch.full((B, L, L), -1, dtype=torch.int32, device=present.device)
         cellmap[idx[:, 0], idx[:, 1], idx[:, 2]] = torch.arange(N, dtype=torch.int32, device=present.device)
-        return CellLayout(cells, row_ptr, cellmap, B, L, idx)
+        return CellLayout(cells, row_ptr, cellmap, B, L, idx, present is flag)
 
     @staticmethod
     def from_mask(moment_mask):

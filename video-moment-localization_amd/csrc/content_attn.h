@@ -1,6 +1,6 @@
 // Launchers of the MFMA attention core (content_attn.hip), used by content_unit.hip.
-// mean_only: write mean_c cchat [N][dl] instead of cchat [N*C][dl] (last layer: only the clip mean is consumed).
-// g_per_cell: dcchat is [N][dl], the same gradient row for every clip of a cell (last layer).
+// cc_rows [N*C][dl] and/or cc_mean [N][dl] = mean_c (either may be NULL).
+// g_per_cell: dcchat is [N][dl], the same gradient row for every clip of a cell; gscale multiplies the gradient rows.
 #pragma once
 #include "gemm.h"
 
@@ -10,13 +10,13 @@ constexpr int ATTN_SPLITS = 16;     // row-range splits per sample of the word-g
 
 int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* cchat, int dl, int Nq, int mean_only);
+                            float* cc_rows, float* cc_mean, int dl, int Nq);
 
 // scratch floats needed by launch_content_attn_bwd for M = N*C rows
 size_t content_attn_bwd_ws_floats(int M, int B, int dl);
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell);
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale);
 
 }  // namespace smin

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 2)
 void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                                   const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                                   const float* __restrict__ shat, const float* __restrict__ qmask,
-                                  float* __restrict__ cchat, int dl, int Nq, int cells_per_chunk, float scale, int mean_only)
+                                  float* __restrict__ cchat, float* __restrict__ ccmean, int dl, int Nq, int cells_per_chunk, float scale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -284,13 +284,14 @@ void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __r
                 fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
             }
             const int d = 8 * kg + 4 * h;
-            if (!mean_only) {
+            if (cchat) {
                 if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
-            } else {                                                // mean over the clips of the quad (padding lanes hold 0)
+            }
+            if (ccmean) {                                           // mean over the clips of the quad (padding lanes hold 0)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o4[q] = (o4[q] + nb<1>(o4[q]) + nb<2>(o4[q]) + nb<3>(o4[q])) * invC;
                 if (g.ok && (lane & 3) == 0 && d < dl)
-                    stg4(cchat + (size_t)(g.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                    stg4(ccmean + (size_t)(g.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
             }
             if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -306,7 +307,7 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
                                   const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                                   const float* __restrict__ shat, const float* __restrict__ qmask,
                                   float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
-                                  int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell)
+                                  int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell, float gscale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int LDM = AttnLds<DL>::LDM, KG = DL / 8;
@@ -350,7 +351,8 @@ void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* _
             const int d = 8 * kg + 4 * h;
             const float4 g4 = gq[kg];
             const bool ok = g.ok && d < dl;
-            const float gv[4] = {ok ? g4.x : 0.f, ok ? g4.y : 0.f, ok ? g4.z : 0.f, ok ? g4.w : 0.f};
+            const float gs = ok ? gscale : 0.f;
+            const float gv[4] = {g4.x * gs, g4.y * gs, g4.z * gs, g4.w * gs};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float x = ch[kg][q], y = gv[q];
@@ -547,23 +549,24 @@ __global__ void content_attn_reduce_kernel(const float* __restrict__ slab, int d
 // ---- launchers --------------------------------------------------------------------------------------------------
 template <int DL>
 static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
-                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask, float* cchat, int dl, int Nq, int mean_only)
+                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                 float* cc_rows, float* cc_mean, int dl, int Nq)
 {
     int cpc, mc; chunking(L, &cpc, &mc);
     hipLaunchKernelGGL((content_attn_fwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(false), st, chat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, cchat, dl, Nq, cpc, 1.0f / sqrtf((float)dl), mean_only);
+                       Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* cchat, int dl, int Nq, int mean_only)
+                            float* cc_rows, float* cc_mean, int dl, int Nq)
 {
-    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
-    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
-    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
-    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, mean_only);
+    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
+    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
+    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
+    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
 }
 
 size_t content_attn_bwd_ws_floats(int M, int B, int dl)
@@ -574,7 +577,7 @@ size_t content_attn_bwd_ws_floats(int M, int B, int dl)
 template <int DL>
 static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell)
+                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale)
 {
     int cpc, mc; chunking(L, &cpc, &mc);
     float* da = ws;
@@ -582,7 +585,7 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
     float* P = dS + (size_t)M * 32;
     float* slab = P + (size_t)M * 32;
     hipLaunchKernelGGL((content_attn_bwd_mfma_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(true), st, chat, dcchat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell);
+                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell, gscale);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL((content_attn_wordgrad_kernel<DL>), dim3(ATTN_SPLITS, B), dim3(256), 0, st, chat, da, dS, P, row_ptr, L, C, dl, ATTN_SPLITS, slab);
     SMIN_LAUNCH_CHECK();
@@ -594,12 +597,68 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell)
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale)
 {
-    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
-    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
-    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
-    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell);
+    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
+    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
+    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
+    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
+}
+
+// g[n][c][:] = dcc[n][c][:] + dccmean[n][:] / C        (both consumers of a middle layer's attention output)
+__global__ void attn_grad_combine_kernel(const float* __restrict__ dcc, const float* __restrict__ dccmean, float* __restrict__ out,
+                                         size_t total4, int C, int dl4, float invC)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const size_t row = idx / dl4; const int d4 = (int)(idx % dl4);
+    stg4(out + idx * 4, f4fma(ldg4(dccmean + ((row / C) * dl4 + d4) * 4), invC, ldg4(dcc + idx * 4)));
 }
 
 }  // namespace smin
+
+using namespace smin;
+
+// The attention core of the content unit on its own (content stream: the unit's two linear maps are applied in the
+// dl-dimensional space by the caller, see content_stream in the Python host).  chat [N*C][dl] -> cc [N*C][dl] and/or
+// ccmean [N][dl] = mean_c cc (either output may be NULL).
+extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int32_t* cells, const int32_t* row_ptr,
+                                     int N, int B, int L, int C, int dl, int Nq,
+                                     const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                                     float* cc, float* ccmean)
+{
+    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32 && (cc || ccmean));
+    if (N == 0) return 0;
+    return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
+}
+
+extern "C" size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl)
+{
+    return sizeof(float) * (content_attn_bwd_ws_floats(N * C, B, dl) + (size_t)N * C * dl + 64);
+}
+
+// Gradients dcc [N*C][dl] and/or dccmean [N][dl] (either may be NULL, not both) -> dchat and the per-sample word-side
+// gradients.  Masked cells (m == 0) get dchat = 0.
+extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float* dccmean, const float* chat,
+                                     const int32_t* cells, const int32_t* row_ptr, int N, int B, int L, int C, int dl, int Nq,
+                                     const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                                     float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32 && (dcc || dccmean));
+    SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));
+    if (N == 0) return 0;
+    const int M = N * C;
+    float* w = reinterpret_cast<float*>(ws);
+    float* aws = w + (((size_t)M * dl + 3) & ~(size_t)3);
+    const float* g = dcc; int per_cell = 0; float gscale = 1.0f;
+    if (dcc && dccmean) {
+        const size_t tot4 = (size_t)M * (dl / 4);
+        hipLaunchKernelGGL(attn_grad_combine_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, st, dcc, dccmean, w, tot4, C, dl / 4, 1.0f / C);
+        SMIN_LAUNCH_CHECK();
+        g = w;
+    } else if (!dcc) {
+        g = dccmean; per_cell = 1; gscale = 1.0f / C;
+    }
+    return launch_content_attn_bwd(st, chat, g, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, per_cell, gscale);
+}

@@ -153,7 +153,7 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
     const int M = N * C;
     int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, C}, M, dl, D);
     if (rc) return rc;
-    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cchat, dl, Nq, last);
+    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, last ? nullptr : cchat, last ? cchat : nullptr, dl, Nq);
     if (rc) return rc;
     if (last)                       // cchat holds mean_c cchat [N][dl]; a quarter of the rows, and fc_out is never written
         return launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpLastMean{bc, cells, fcmean_in, hbar, fcmean}, N, D, dl);
@@ -211,7 +211,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     rc = launch_reduce_slabs(st, slab1, dWc, D * dl, sp1); if (rc) return rc;
     rc = launch_reduce_slabs(st, bslab1, dbc, D, sp1); if (rc) return rc;
     // (c) attention core backward -> dchat (already multiplied by m: masked cells write 0)
-    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last);
+    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f);
     if (rc) return rc;
     // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl;  dhbar = sum_c dout (gate term)
     if (C == 4) {

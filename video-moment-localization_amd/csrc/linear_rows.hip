@@ -1,0 +1,92 @@
+// Row-wise linear maps of the content stream:  y[r][:] = x[r][:] W^T + bias + add_rows[r][:] + add_cells[r / C][:]
+// on the fp32 MFMA engine (gemm.h), forward and backward.  In the content stream (see the Python host) the content
+// unit's two linear maps (reference models.py:247, 269) are composed in the dl-dimensional space, so every
+// contraction here has K or N equal to dl instead of D.
+#include "gemm.h"
+#include "smin_hip.h"
+
+namespace smin {
+
+struct EpLinearRows {
+    const float* bias; const float* add_rows; const float* add_cells; int C; float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            if (bias) v = f4add(v, ldg4(bias + col));
+            if (add_rows) v = f4add(v, ldg4(add_rows + (size_t)row * N + col));
+            if (add_cells) v = f4add(v, ldg4(add_cells + (size_t)(row / C) * N + col));
+            stg4(out + (size_t)row * N + col, v);
+        });
+    }
+};
+struct EpStoreRows {
+    float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+    }
+};
+
+// out[g][:] = sum_{c < C} x[g*C + c][:]
+__global__ void group_sum_kernel(const float* __restrict__ x, float* __restrict__ out, size_t groups, int C, int W4)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= groups * W4) return;
+    const size_t g = idx / W4; const int d4 = (int)(idx % W4);
+    float4 s = f4zero();
+    for (int c = 0; c < C; ++c) s = f4add(s, ldg4(x + ((g * C + c) * W4 + d4) * 4));
+    stg4(out + idx * 4, s);
+}
+
+}  // namespace smin
+
+using namespace smin;
+
+extern "C" int smin_linear_rows_fwd(void* stream, const float* x, const float* W, const float* bias, const float* add_rows,
+                                    const float* add_cells, int C, int R, int O, int K, float* y)
+{
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1);
+    if (R == 0) return 0;
+    return launch_gemm_nt((hipStream_t)stream, PlainMat{x, K}, PlainMat{W, K}, EpLinearRows{bias, add_rows, add_cells, C, y}, R, O, K);
+}
+
+extern "C" size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int K)
+{
+    const int sp = R > 0 ? tn_splits(R, O, K) : 1;
+    return sizeof(float) * ((size_t)sp * O * K + (size_t)sp * O + 64);
+}
+
+// dx = dy W (NULL to skip), dW = dy^T x, dbias = colsum(dy) (NULL to skip).  WT is W^T [K][O], row-major.
+extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* x, const float* WT, int R, int O, int K,
+                                    float* dx, float* dW, float* dbias, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0);
+    if (R == 0) {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * K, st);
+        if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)O, st);
+        return 0;
+    }
+    SMIN_REQUIRE(ws_bytes >= smin_linear_rows_bwd_workspace_bytes(R, O, K));
+    int rc;
+    if (dx) {
+        rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows{dx}, R, K, O);
+        if (rc) return rc;
+    }
+    const int sp = tn_splits(R, O, K);
+    float* slab = reinterpret_cast<float*>(ws);
+    float* bslab = slab + (size_t)sp * O * K;
+    rc = launch_gemm_tn(st, PlainMat{dy, O}, PlainMat{x, K}, slab, bslab, R, O, K, sp);
+    if (rc) return rc;
+    rc = launch_reduce_slabs(st, slab, dW, O * K, sp); if (rc) return rc;
+    if (dbias) { rc = launch_reduce_slabs(st, bslab, dbias, O, sp); if (rc) return rc; }
+    return 0;
+}
+
+extern "C" int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out)
+{
+    SMIN_REQUIRE(W % 4 == 0 && C >= 1);
+    if (groups == 0) return 0;
+    const size_t tot = (size_t)groups * (W / 4);
+    hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, (size_t)groups, C, W / 4);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}

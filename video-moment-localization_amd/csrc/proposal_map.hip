@@ -53,10 +53,10 @@ void proposal_map_fwd_kernel(const double* __restrict__ Pf, const int* __restric
                 v.x = (float)((pe[0] - ps[0]) * inv); v.y = (float)((pe[1] - ps[1]) * inv);
                 v.z = (float)((pe[2] - ps[2]) * inv); v.w = (float)((pe[3] - ps[3]) * inv);
             }
-            stg4(fc + ((size_t)n * C + c) * D + d, v);
+            if (fc) stg4(fc + ((size_t)n * C + c) * D + d, v);
             sum = f4add(sum, v);
         }
-        stg4(fm + (size_t)n * D + d, make_float4(sum.x / C, sum.y / C, sum.z / C, sum.w / C));
+        if (fm) stg4(fm + (size_t)n * D + d, make_float4(sum.x / C, sum.y / C, sum.z / C, sum.w / C));
     }
 }
 
@@ -76,10 +76,31 @@ __global__ void boundary_pool_fwd_kernel(const float* __restrict__ f, int T, int
     stg4(fb + idx * 4, make_float4(s.x / fr, s.y / fr, s.z / fr, s.w / fr));
 }
 
+// where the clip gradient rows come from: one [N*C][D] tensor, or nseg tensors [N*C][W] side by side (D = nseg*W)
+struct DenseClipGrad {
+    const float* dfc;
+    __device__ __forceinline__ bool any() const { return dfc != nullptr; }
+    __device__ __forceinline__ int width(int D) const { return D; }
+    __device__ __forceinline__ float4 load(size_t row, int d, int D) const { return ldg4(dfc + row * D + d); }
+};
+struct SegClipGrad {
+    const float* seg[8]; int W;
+    __device__ __forceinline__ bool any() const { return true; }
+    __device__ __forceinline__ int width(int) const { return W; }
+    __device__ __forceinline__ float4 load(size_t row, int d, int) const {
+        const int sg = d / W;                                       // a select chain, not an indexed read of the argument block
+        const float* p = seg[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) p = sg == k ? seg[k] : p;
+        return ldg4(p + row * W + (d - sg * W));
+    }
+};
+
 // E[b][t][:] = sum over clips starting at t of g/cs  -  sum over clips ending at t of g/cs,
 // g = m * (dfc[n][c][:] + dfm[n][:] / C).  One workgroup per (b, t); deterministic (pure gather).
+template <class Src>
 __global__ __launch_bounds__(128)
-void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* __restrict__ dfm,
+void proposal_map_bwd_events_kernel(Src src, const float* __restrict__ dfm,
                                     const int* __restrict__ cells, const int* __restrict__ cellmap,
                                     int T, int L, int C, int D, float* __restrict__ E)
 {
@@ -105,7 +126,7 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
             const int d = threadIdx.x * 4 + 512 * k;
             if (d < D) {
                 float4 g = f4zero();
-                if (dfc) g = ldg4(dfc + ((size_t)n * C + c) * D + d);
+                if (src.any()) g = src.load((size_t)n * C + c, d, D);
                 if (dfm && with_m) g = f4fma(ldg4(dfm + (size_t)n * D + d), invC, g);
                 acc[k] = f4fma(g, sc, acc[k]);
             }
@@ -140,101 +161,155 @@ void proposal_map_bwd_events_kernel(const float* __restrict__ dfc, const float* 
     }
 }
 
-// Same result as proposal_map_bwd_events_kernel, organised for the machine: the clip equations of the start-snippet
-// rows are solved by one LANE per row (the version above has every thread of the workgroup repeat the whole scalar
-// search: ~25k integer instructions per workgroup), each lane leaving its events {cell, clip, +-1/cs, with-mean} in a
-// fixed slot range of an LDS list; the row that starts exactly at frame t (one event per window width) gets a list
-// of its own.  Then all threads stream the lists in (row, slot) order -- the order is fixed, so the sum is
-// bitwise reproducible -- with the dependent cellmap / mask lookups already resolved.
-constexpr int EV_SLOTS = 16;
-struct Ev { int nc; float sc; };                      // nc = (cell << 3) | (with_mean << 2 ... ) see pack below
+// Same result as proposal_map_bwd_events_kernel, organised for the machine.
+//
+// Which clips of which cells (i, j) start or end at frame t depends only on (T, L, C) -- it is the sparsity pattern of
+// the reference's content matrix Wc (models.py:88-98, a module buffer built once).  clip_event_table_kernel lists it
+// once per geometry: a cell (i, w = j-i+1) has a clip boundary at t exactly when base = t - i*r is a multiple q of its
+// clip size cs: clip q starts there if q < nclip, clip q-1 ends there if 1 <= q <= nclip.  The table is tiny
+// (2 * sum nclip entries of 8 bytes) and shared by every sample and every call.
+// Per call, one workgroup per (b, t) reads its frame's entries, resolves (i, j) through the sample's cellmap (and the
+// mask) and compacts the hits into per-wave LDS lists by ballot rank -- a fixed order, so the sum is bitwise
+// reproducible.  Streaming phase: a gradient row is `lanes` float4 wide per slot (slot = one 512-float chunk of a
+// dense row, or one segment); the 128 threads form 128 / lanes groups that take alternate batches of UNR events, each
+// with UNR x NS independent row loads in flight -- the phase is bound by HBM latency per step, not by bytes.  The
+// groups' partial sums are combined through LDS in group order.
+constexpr int EV_CAP = 512;                            // events per wave list per round
+struct Ev { int nc; float sc; };                       // table: nc = (i << 18) | (j << 6) | (with_mean << 3) | clip
+                                                       // resolved: nc = (cell << 4) | (with_mean << 3) | clip
 
-__global__ __launch_bounds__(128)
-void proposal_map_bwd_events2_kernel(const float* __restrict__ dfc, const float* __restrict__ dfm,
-                                     const int* __restrict__ cells, const int* __restrict__ cellmap,
-                                     int T, int L, int C, int D, float* __restrict__ E)
+// grid T, one wave per frame.  table == nullptr: counts[t] = number of entries; else fill table[offsets[t] ...].
+__global__ __launch_bounds__(64)
+void clip_event_table_kernel(int T, int L, int C, int* __restrict__ counts, const int* __restrict__ offsets, Ev* __restrict__ table)
 {
-    extern __shared__ __attribute__((aligned(8))) unsigned char lds_raw[];
-    Ev* rowev = reinterpret_cast<Ev*>(lds_raw);                    // [L][EV_SLOTS]
-    Ev* zeroev = rowev + (size_t)L * EV_SLOTS;                      // [L]      events of the row with base == 0
-    int* cnt = reinterpret_cast<int*>(zeroev + L);                  // [L]
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int t = blockIdx.x, lane = threadIdx.x;
     const int r = T / L;
+    const int imax = min(L - 1, t / r);
+    const int npairs = (imax + 1) * L;
+    Ev* out = table ? table + offsets[t] : nullptr;
+    int wn = 0;
+    for (int p0 = 0; p0 < npairs; p0 += 64) {
+        const int p = p0 + lane;
+        bool s_ev = false, e_ev = false;
+        int i = 0, j = 0, q = 0, nclip = 0;
+        float inv = 0.f;
+        if (p < npairs) {
+            i = p / L;
+            const int w = p - i * L + 1;
+            j = i + w - 1;
+            if (j < L) {
+                const int nf = w * r, cs = max(1, nf / C), base = t - i * r;
+                nclip = min(C, nf);
+                q = base / cs;
+                if (q * cs == base) { s_ev = q < nclip; e_ev = q >= 1 && q <= nclip; }
+                inv = 1.0f / (float)cs;
+            }
+        }
+        const int key = (i << 18) | (j << 6);
+        unsigned long long m = __ballot(s_ev);
+        if (s_ev && out) out[wn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+                             Ev{key | ((q == 0) << 3) | q, inv};
+        wn += __popcll(m);
+        m = __ballot(e_ev);
+        if (e_ev && out) out[wn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+                             Ev{key | ((q == nclip) << 3) | (q - 1), -inv};
+        wn += __popcll(m);
+    }
+    if (!table && lane == 0) counts[t] = wn;
+}
+
+template <class Src, int NS, int UNR, bool HAS_M>
+__global__ __launch_bounds__(128)
+void proposal_map_bwd_events2_kernel(Src src, const float* __restrict__ dfm,
+                                     const int* __restrict__ cells, const int* __restrict__ cellmap,
+                                     const int* __restrict__ ev_off, const Ev* __restrict__ ev_tab,
+                                     int T, int L, int C, int D, float* __restrict__ E, int check_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Ev* list = reinterpret_cast<Ev*>(lds_raw);                      // [2][EV_CAP]
+    int* wcnt = reinterpret_cast<int*>(list + 2 * EV_CAP);          // [2] events in each wave's list
+    float4* red = reinterpret_cast<float4*>(lds_raw + 2 * EV_CAP * sizeof(Ev) + 16);   // [128][NS]
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int* cmap = cellmap + (size_t)b * L * L;
     const float invC = 1.0f / C;
-    const int imax = min(L - 1, t / r);
-    const int i0 = (t % r == 0 && t / r < L) ? t / r : -1;          // row whose window starts at frame t
+    const int e0 = ev_off[t], ne = ev_off[t + 1] - e0;
 
-    auto lookup = [&](int i, int w) -> int {                        // cell id of (i, i+w-1) if present and unmasked
-        const int j = i + w - 1;
-        if (j >= L) return -1;
-        const int n = cmap[i * L + j];
-        if (n < 0 || cells[4 * (size_t)n + 3] == 0) return -1;
-        return n;
-    };
-    for (int i = tid; i < L; i += 128) {
-        int k = 0;
-        if (i <= imax && i != i0) {
-            const int base = t - i * r;
-            auto widths = [&](int c, int cs, float sign) {
-                int lo = (cs * C + r - 1) / r, hi = ((cs + 1) * C + r - 1) / r - 1;
-                if (cs == 1) lo = 1;
-                lo = max(lo, c / r + 1);
-                hi = min(hi, L - i);
-                for (int w = lo; w <= hi; ++w) {
-                    const int n = lookup(i, w);
-                    if (n >= 0 && k < EV_SLOTS) {
-                        const int with_m = (sign < 0.f && c + 1 == min(C, w * r)) ? 1 : 0;
-                        rowev[i * EV_SLOTS + k++] = Ev{(n << 4) | (with_m << 3) | c, sign / (float)cs};
+    const int W = src.width(D);
+    const int lanes = min(128, W / 4), groups = 128 / lanes;
+    const int grp = tid / lanes, ln = tid - grp * lanes;
+    const int nslot = (D + 4 * lanes - 1) / (4 * lanes);
+    const bool active = grp < groups;
+    float4 acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = f4zero();
+
+    for (int base = 0; base < ne; base += 2 * EV_CAP) {
+        // resolve this round's table entries: (i, j) -> packed cell index, dropping absent and masked cells
+        int wn = 0;
+        Ev* mine = list + wave * EV_CAP;
+        const int lo = base + wave * EV_CAP, hi = min(ne, lo + EV_CAP);
+        for (int x0 = lo; x0 < hi; x0 += 64) {
+            const int x = x0 + lane;
+            Ev e = Ev{0, 0.f};
+            int n = -1;
+            if (x < hi) {
+                e = ev_tab[e0 + x];
+                n = cmap[(e.nc >> 18) * L + ((e.nc >> 6) & 4095)];
+                if (n >= 0 && check_mask && cells[4 * (size_t)n + 3] == 0) n = -1;
+            }
+            const unsigned long long m = __ballot(n >= 0);
+            if (n >= 0) mine[wn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+                            Ev{(n << 4) | (e.nc & 15), e.sc};
+            wn += __popcll(m);
+        }
+        if (lane == 0) wcnt[wave] = wn;
+        __syncthreads();
+        const int n0 = wcnt[0], n1 = wcnt[1];
+        auto event = [&](int e) -> Ev { return e < n0 ? list[e] : list[EV_CAP + (e - n0)]; };
+        if (active)
+            for (int q0 = grp * UNR; q0 < n0 + n1; q0 += groups * UNR) {
+                const int cntk = min(UNR, n0 + n1 - q0);
+                float4 gc[UNR][NS], gm[UNR][NS];
+                float sc[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const Ev e = event(q0 + min(u, cntk - 1));
+                    const bool ok = u < cntk && e.nc >= 0;
+                    const int n = ok ? e.nc >> 4 : 0, c = e.nc & 7;
+                    sc[u] = ok ? e.sc : 0.f;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int d = (k * lanes + ln) * 4;
+                        const bool dok = ok && k < nslot && d < D;
+                        gc[u][k] = (src.any() && dok) ? src.load((size_t)n * C + c, d, D) : f4zero();
+                        if (HAS_M) gm[u][k] = (dok && (e.nc & 8)) ? ldg4(dfm + (size_t)n * D + d) : f4zero();
                     }
                 }
-            };
-            for (int c = 1; c < C; ++c) if (base % c == 0) widths(c, base / c, 1.0f);
-            for (int cc = 1; cc <= C; ++cc) if (base % cc == 0) widths(cc - 1, base / cc, -1.0f);
-        }
-        cnt[i] = k;
-    }
-    if (i0 >= 0)
-        for (int w = tid + 1; w <= L - i0; w += 128) {
-            const int n = lookup(i0, w);
-            zeroev[w - 1] = Ev{n >= 0 ? ((n << 4) | 8) : -1, 1.0f / (float)max(1, (w * r) / C)};
-        }
-    __syncthreads();
-
-    float4 acc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = f4zero();
-    // four events per step: their row loads are independent, so eight HBM requests are in flight per lane
-    auto apply4 = [&](const Ev* ev, int cnt4) {
-        float4 gc[4], gm[4];
-        float sc[4];
+                for (int u = 0; u < UNR; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = acc[k];
-        for (int kd = 0; kd < 4; ++kd) {
-            const int d = tid * 4 + 512 * kd;
-            if (d >= D) break;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const Ev e = ev[min(u, cnt4 - 1)];
-                const bool ok = u < cnt4 && e.nc >= 0;
-                const int n = ok ? e.nc >> 4 : 0, c = e.nc & 7;
-                sc[u] = ok ? e.sc : 0.f;
-                gc[u] = (dfc && ok) ? ldg4(dfc + ((size_t)n * C + c) * D + d) : f4zero();
-                gm[u] = (dfm && ok && (e.nc & 8)) ? ldg4(dfm + (size_t)n * D + d) : f4zero();
+                    for (int k = 0; k < NS; ++k)
+                        acc[k] = f4fma(HAS_M ? f4fma(gm[u][k], invC, gc[u][k]) : gc[u][k], sc[u], acc[k]);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[kd] = f4fma(f4fma(gm[u], invC, gc[u]), sc[u], acc[kd]);
-        }
-    };
-    for (int i = 0; i <= imax; ++i) {
-        const Ev* list = i == i0 ? zeroev : rowev + (size_t)i * EV_SLOTS;
-        const int k = i == i0 ? L - i0 : cnt[i];
-        for (int q = 0; q < k; q += 4) apply4(list + q, min(4, k - q));
+        __syncthreads();                                            // the lists are rebuilt in the next round
     }
+    if (groups > 1) {
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int d = tid * 4 + 512 * k;
-        if (d < D) stg4(E + ((size_t)b * T + t) * D + d, acc[k]);
+        for (int k = 0; k < NS; ++k) red[tid * NS + k] = acc[k];
+        __syncthreads();
+        if (grp == 0)
+            for (int g = 1; g < groups; ++g)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) acc[k] = f4add(acc[k], red[(g * lanes + ln) * NS + k]);
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int d = (k * lanes + ln) * 4;
+            if (k < nslot && d < D) stg4(E + ((size_t)b * T + t) * D + d, acc[k]);
+        }
     }
 }
 
@@ -271,41 +346,169 @@ extern "C" int smin_proposal_map_fwd(void* stream, const float* f, const int32_t
     double* Pf = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(time_prefix_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, f, Pf, B, T, D);
     SMIN_LAUNCH_CHECK();
-    if (N > 0) {
+    if (N > 0 && (fc || fm)) {
         hipLaunchKernelGGL(proposal_map_fwd_kernel, dim3(N), dim3(128), 0, st, Pf, cells, T, L, C, D, fc, fm);
         SMIN_LAUNCH_CHECK();
     }
-    const size_t tot = (size_t)B * L * (D / 4);
-    hipLaunchKernelGGL(boundary_pool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f, T, L, D / 4, fb, tot);
+    if (fb) {
+        const size_t tot = (size_t)B * L * (D / 4);
+        hipLaunchKernelGGL(boundary_pool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f, T, L, D / 4, fb, tot);
+        SMIN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static bool events2_ok(int N, int T, int L, int C, size_t* lds)
+{
+    (void)T;
+    *lds = 2 * EV_CAP * sizeof(Ev) + 16;                           // + the group-reduction buffer, see launch_events2
+    return C <= 8 && L <= 4096 && N < (1 << 27);
+}
+
+template <class Src, int NS, int UNR, bool HAS_M>
+static int launch_events2_t(hipStream_t st, const Src& src, const float* dfm, const int32_t* cells, const int32_t* cellmap,
+                            const int32_t* ev_off, const Ev* ev_tab, int B, int T, int L, int C, int D, float* E, size_t lds)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_map_bwd_events2_kernel<Src, NS, UNR, HAS_M>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((proposal_map_bwd_events2_kernel<Src, NS, UNR, HAS_M>), dim3(T, B), dim3(128), lds, st, src, dfm, cells, cellmap, ev_off, ev_tab, T, L, C, D, E, 1);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+// W = width of one gradient row segment (D for a dense source)
+template <class Src>
+static int launch_events2(hipStream_t st, const Src& src, const float* dfm, const int32_t* cells, const int32_t* cellmap,
+                          const int32_t* ev_off, const Ev* ev_tab, int B, int T, int L, int C, int D, int W, float* E, size_t lds)
+{
+    const int lanes = W / 4 < 128 ? W / 4 : 128;
+    const int nslot = cdiv(D, 4 * lanes);
+    if (128 / lanes > 1) lds += (size_t)128 * 16 * (nslot == 1 ? 1 : nslot <= 4 ? 4 : 8);
+    if (dfm) {
+        if (nslot == 1) return launch_events2_t<Src, 1, 8, true>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+        if (nslot <= 4) return launch_events2_t<Src, 4, 2, true>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+        return launch_events2_t<Src, 8, 1, true>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+    }
+    if (nslot == 1) return launch_events2_t<Src, 1, 8, false>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+    if (nslot <= 4) return launch_events2_t<Src, 4, 4, false>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+    return launch_events2_t<Src, 8, 2, false>(st, src, dfm, cells, cellmap, ev_off, ev_tab, B, T, L, C, D, E, lds);
+}
+
+// The clip-boundary table of a geometry (T, L, C): call once with table == NULL to get counts[T], build the exclusive
+// prefix offsets[T + 1] on the caller's side, then call again to fill table[offsets[T]] (8-byte entries).
+extern "C" int smin_clip_event_table(void* stream, int T, int L, int C, int32_t* counts, const int32_t* offsets, void* table)
+{
+    SMIN_REQUIRE(L >= 1 && T >= L && T % L == 0 && C >= 1 && C <= 8 && L <= 4096);
+    SMIN_REQUIRE((table == nullptr) != (counts == nullptr));
+    hipLaunchKernelGGL(clip_event_table_kernel, dim3(T), dim3(64), 0, (hipStream_t)stream, T, L, C, counts, offsets, reinterpret_cast<Ev*>(table));
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, const float* dfb,
                                         const int32_t* cells, const int32_t* row_ptr, const int32_t* cellmap,
-                                        int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes)
+                                        int N, int B, int T, int L, int C, int D, float* df, void* ws, size_t ws_bytes,
+                                        const int32_t* ev_offsets, const void* ev_table)
 {
+    (void)row_ptr;
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && L >= 1 && T >= L && T % L == 0 && C >= 1 && D <= 2048);
     float* E = nullptr;
     if (N > 0 && (dfc || dfm)) {
         SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * T * D);
         E = reinterpret_cast<float*>(ws);
-        const int r = T / L;
-        const size_t lds = (size_t)L * EV_SLOTS * 8 + (size_t)L * 8 + (size_t)L * 4;
-        if (2 * C * cdiv(C, r) <= EV_SLOTS && C <= 8 && N < (1 << 27) && lds <= 150 * 1024) {
-            if (lds > 48 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_map_bwd_events2_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
-            }
-            hipLaunchKernelGGL(proposal_map_bwd_events2_kernel, dim3(T, B), dim3(128), lds, st, dfc, dfm, cells, cellmap, T, L, C, D, E);
+        size_t lds;
+        if (ev_table && ev_offsets && events2_ok(N, T, L, C, &lds)) {
+            const int rc = launch_events2(st, DenseClipGrad{dfc}, dfm, cells, cellmap, ev_offsets, reinterpret_cast<const Ev*>(ev_table), B, T, L, C, D, D, E, lds);
+            if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(proposal_map_bwd_events_kernel, dim3(T, B), dim3(128), 0, st, dfc, dfm, cells, cellmap, T, L, C, D, E);
+            hipLaunchKernelGGL((proposal_map_bwd_events_kernel<DenseClipGrad>), dim3(T, B), dim3(128), 0, st, DenseClipGrad{dfc}, dfm, cells, cellmap, T, L, C, D, E);
+            SMIN_LAUNCH_CHECK();
         }
-        SMIN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, dfb, B, T, L, D, df);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Clip means of per-frame features g [B][T][nseg*W] over every cell's clip windows, plus a bias on every clip row
+// (empty clips included), one output tensor per segment of W features:
+//   out[s][n*C + c][:] = m * (mean_{t in clip c of cell n} g[b][t][s*W : (s+1)*W] + bias[s*W : (s+1)*W])
+// With g = f [Wch_1; ..; Wch_k]^T this is every layer's linear_c_hat applied to ProposalGeneration's f_c without ever
+// forming f_c (content stream).  Backward: smin_clip_window_means_bwd.
+__global__ void clip_window_means_kernel(const double* __restrict__ Pf, const float* __restrict__ bias, const int* __restrict__ cells,
+                                         int T, int L, int C, int W, int nseg, size_t rows, float* __restrict__ out)
+{
+    const int W4 = W / 4, D = W * nseg;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * W4 * nseg) return;
+    const int d4 = (int)(idx % W4);
+    const size_t row = (idx / W4) % rows;
+    const int sg = (int)(idx / ((size_t)W4 * rows));
+    const size_t n = row / C; const int c = (int)(row % C);
+    const Cell cl = load_cell(cells, n);
+    const int r = T / L, w = cl.j - cl.i + 1, nf = w * r, cs = max(1, nf / C);
+    const int nclip = (cl.m != 0 && w >= 1) ? min(C, nf) : 0;
+    const int d = sg * W + d4 * 4;
+    float4 v = f4zero();
+    if (c < nclip) {
+        const double inv = (double)(1.0f / (float)cs);
+        const int s0 = cl.i * r + c * cs;
+        const double* ps = Pf + ((size_t)cl.b * (T + 1) + s0) * D + d;
+        const double* pe = ps + (size_t)cs * D;
+        v = make_float4((float)((pe[0] - ps[0]) * inv), (float)((pe[1] - ps[1]) * inv), (float)((pe[2] - ps[2]) * inv), (float)((pe[3] - ps[3]) * inv));
+    }
+    if (bias && cl.m != 0) v = f4add(v, ldg4(bias + d));
+    stg4(out + ((size_t)sg * rows + row) * W + d4 * 4, v);
+}
+
+
+extern "C" int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias, const int32_t* cells, int N, int B, int T, int L, int C,
+                                          int W, int nseg, float* out, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int D = W * nseg;
+    SMIN_REQUIRE(W % 4 == 0 && nseg >= 1 && nseg <= 8 && L >= 1 && T >= L && T % L == 0 && C >= 1 && D <= 2048);
+    SMIN_REQUIRE(ws_bytes >= sizeof(double) * (size_t)B * (T + 1) * D);
+    if (N == 0) return 0;
+    double* Pf = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(time_prefix_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, g, Pf, B, T, D);
+    SMIN_LAUNCH_CHECK();
+    const size_t rows = (size_t)N * C, tot = rows * (W / 4) * nseg;
+    hipLaunchKernelGGL(clip_window_means_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Pf, bias, cells, T, L, C, W, nseg, rows, out);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+// dg [B][T][nseg*W] from the nseg gradient tensors dout[s] [N*C][W] (host array of device pointers).
+extern "C" int smin_clip_window_means_bwd(void* stream, const float* const* dout, const int32_t* cells, const int32_t* row_ptr,
+                                          const int32_t* cellmap, int N, int B, int T, int L, int C, int W, int nseg, float* dg,
+                                          void* ws, size_t ws_bytes, const int32_t* ev_offsets, const void* ev_table)
+{
+    (void)row_ptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = W * nseg;
+    SMIN_REQUIRE(W % 4 == 0 && nseg >= 1 && nseg <= 8 && L >= 1 && T >= L && T % L == 0 && C >= 1 && D <= 2048);
+    float* E = nullptr;
+    if (N > 0) {
+        SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * T * D);
+        E = reinterpret_cast<float*>(ws);
+        size_t lds;
+        SegClipGrad src;
+        for (int k = 0; k < 8; ++k) src.seg[k] = dout[k < nseg ? k : 0];
+        src.W = W;
+        if (ev_table && ev_offsets && events2_ok(N, T, L, C, &lds) && W <= 512) {
+            const int rc = launch_events2(st, src, nullptr, cells, cellmap, ev_offsets, reinterpret_cast<const Ev*>(ev_table), B, T, L, C, D, W, E, lds);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL((proposal_map_bwd_events_kernel<SegClipGrad>), dim3(T, B), dim3(128), 0, st, src, (const float*)nullptr, cells, cellmap, T, L, C, D, E);
+            SMIN_LAUNCH_CHECK();
+        }
+    }
+    hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, (const float*)nullptr, B, T, L, D, dg);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

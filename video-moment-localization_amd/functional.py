@@ -39,6 +39,26 @@ def _unit_ws(layout, C, D, dl, Nq, device):
     return _ws(n, device)
 
 
+_EVENT_TABLES = {}
+
+
+def clip_event_table(device, T, L, C):
+    """The geometry's clip-boundary table (offsets int32 [T+1], entries int32 [n, 2]), built once per (device, T, L, C)
+    and kept -- the counterpart of the reference's cached ``self.Wc`` buffer (models.py:110), 8 bytes per clip
+    boundary instead of a dense (L, L, C, T) matrix."""
+    key = (device.type, device.index, T, L, C)
+    tab = _EVENT_TABLES.get(key)
+    if tab is None:
+        counts = torch.empty(T, dtype=torch.int32, device=device)
+        call("smin_clip_event_table", stream(), T, L, C, ptr(counts), None, None)
+        offsets = torch.zeros(T + 1, dtype=torch.int32, device=device)
+        offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        table = torch.empty((max(1, int(offsets[-1])), 2), dtype=torch.int32, device=device)
+        call("smin_clip_event_table", stream(), T, L, C, None, ptr(offsets), ptr(table))
+        tab = _EVENT_TABLES[key] = (offsets, table)
+    return tab
+
+
 class ProposalMapFn(Function):
     """ProposalGeneration.forward (reference models.py:115-126)."""
 
@@ -64,9 +84,151 @@ class ProposalMapFn(Function):
         ref = dfc if dfc is not None else dfm if dfm is not None else dfb
         df = ref.new_empty((B, T, D))
         _, wp, wn = _ws(4 * B * T * D, df.device)
+        eo, et = clip_event_table(df.device, T, L, C)
         call("smin_proposal_map_bwd", stream(), ptr(dfc), ptr(dfm), ptr(dfb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
-             layout.N, B, T, L, C, D, ptr(df), wp, wn)
+             layout.N, B, T, L, C, D, ptr(df), wp, wn, ptr(eo), ptr(et))
         return df, None, None, None, None
+
+
+class ProposalMeansFn(Function):
+    """ProposalGeneration.forward without f_c: (f_m, f_b) only (content stream; f_c is never formed)."""
+
+    @staticmethod
+    def forward(ctx, f, layout, T, L, C):
+        f = _c(f)
+        B, Tn, D = f.shape
+        if Tn != T:
+            raise ValueError(f"ProposalGeneration was built for T={T} but got {Tn} frames")
+        fm = f.new_empty((layout.N, D))
+        fb = f.new_empty((B, L, D))
+        _, wp, wn = _ws(8 * B * (T + 1) * D, f.device)
+        call("smin_proposal_map_fwd", stream(), ptr(f), ptr(layout.cells), layout.N, B, T, L, C, D, None, ptr(fm), ptr(fb), wp, wn)
+        ctx.layout, ctx.dims = layout, (B, T, L, C, D)
+        return fm, fb
+
+    @staticmethod
+    def backward(ctx, dfm, dfb):
+        layout = ctx.layout
+        B, T, L, C, D = ctx.dims
+        dfm, dfb = _c(dfm), _c(dfb)
+        ref = dfm if dfm is not None else dfb
+        df = ref.new_empty((B, T, D))
+        _, wp, wn = _ws(4 * B * T * D, df.device)
+        eo, et = clip_event_table(df.device, T, L, C)
+        call("smin_proposal_map_bwd", stream(), None, ptr(dfm), ptr(dfb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
+             layout.N, B, T, L, C, D, ptr(df), wp, wn, ptr(eo), ptr(et))
+        return df, None, None, None, None
+
+
+class ClipWindowMeansFn(Function):
+    """out[s][n, c] = mean over clip c of cell n of g[b, t, s*W:(s+1)*W] + bias[s*W:(s+1)*W], one tensor per segment s
+    -- every layer's linear_c_hat applied to ProposalGeneration's f_c (reference models.py:117, 247) through
+    g = f [Wch_1; ..]^T, without forming f_c.  Mask-driven layouts only."""
+
+    @staticmethod
+    def forward(ctx, g, bias, layout, T, L, C, nseg):
+        g, bias = _c(g), _c(bias)
+        B, Tn, D = g.shape
+        W = D // nseg
+        out = g.new_empty((nseg, layout.N * C, W))
+        _, wp, wn = _ws(8 * B * (T + 1) * D, g.device)
+        call("smin_clip_window_means_fwd", stream(), ptr(g), ptr(bias), ptr(layout.cells), layout.N, B, T, L, C, W, nseg, ptr(out), wp, wn)
+        ctx.layout, ctx.dims = layout, (B, T, L, C, W, nseg)
+        return tuple(out[s] for s in range(nseg))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        import ctypes
+        layout = ctx.layout
+        B, T, L, C, W, nseg = ctx.dims
+        ref = next(d for d in douts if d is not None)
+        douts = [_c(d) if d is not None else ref.new_zeros((layout.N * C, W)) for d in douts]
+        dg = ref.new_empty((B, T, W * nseg))
+        _, wp, wn = _ws(4 * B * T * W * nseg, ref.device)
+        arr = (ctypes.c_void_p * nseg)(*[d.data_ptr() for d in douts])
+        eo, et = clip_event_table(ref.device, T, L, C)
+        call("smin_clip_window_means_bwd", stream(), arr, ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
+             layout.N, B, T, L, C, W, nseg, ptr(dg), wp, wn, ptr(eo), ptr(et))
+        dbias = torch.cat([d.sum(dim=0) for d in douts]) if ctx.needs_input_grad[1] else None
+        return dg, dbias, None, None, None, None, None
+
+
+class ContentAttnFn(Function):
+    """The content unit's attention core alone (reference models.py:252-267): chat [N*C, dl] -> (cc [N*C, dl],
+    ccmean [N, dl] = mean_c cc).  want_rows=False (last layer) returns an empty cc."""
+
+    @staticmethod
+    def forward(ctx, chat, Mq, uq, what, shat, qmask, layout, C, want_rows):
+        chat, Mq, uq, what, shat, qmask = map(_c, (chat, Mq, uq, what, shat, qmask))
+        B, Nq, dl = what.shape
+        N = layout.N
+        cc = chat.new_empty((N * C, dl) if want_rows else (0, dl))
+        ccmean = chat.new_empty((N, dl))
+        call("smin_content_attn_fwd", stream(), ptr(chat), ptr(layout.cells), ptr(layout.row_ptr), N, B, layout.L, C, dl, Nq,
+             ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask), ptr(cc) if want_rows else None, ptr(ccmean))
+        ctx.save_for_backward(chat, Mq, uq, what, shat, qmask)
+        ctx.layout, ctx.C, ctx.want_rows = layout, C, want_rows
+        if not want_rows:
+            ctx.mark_non_differentiable(cc)
+        return cc, ccmean
+
+    @staticmethod
+    def backward(ctx, dcc, dccmean):
+        chat, Mq, uq, what, shat, qmask = ctx.saved_tensors
+        layout, C = ctx.layout, ctx.C
+        B, Nq, dl = what.shape
+        N = layout.N
+        dcc = _c(dcc) if ctx.want_rows else None
+        dccmean = _c(dccmean)
+        if dcc is None and dccmean is None:
+            dccmean = chat.new_zeros((N, dl))
+        dchat = torch.empty_like(chat)
+        dMq, duq, dwhat, dshat = torch.empty_like(Mq), torch.empty_like(uq), torch.empty_like(what), torch.empty_like(shat)
+        if N == 0:
+            for t in (dMq, duq, dwhat, dshat):
+                t.zero_()
+        else:
+            _, wp, wn = _ws(_lib.load().smin_content_attn_bwd_workspace_bytes(N, B, C, dl), chat.device)
+            call("smin_content_attn_bwd", stream(), ptr(dcc), ptr(dccmean), ptr(chat), ptr(layout.cells), ptr(layout.row_ptr),
+                 N, B, layout.L, C, dl, Nq, ptr(Mq), ptr(uq), ptr(what), ptr(shat), ptr(qmask),
+                 ptr(dchat), ptr(dMq), ptr(duq), ptr(dwhat), ptr(dshat), wp, wn)
+        return dchat, dMq, duq, dwhat, dshat, None, None, None, None
+
+
+class LinearRowsFn(Function):
+    """y[r] = x[r] W^T + bias + add_rows[r] + add_cells[r // C]   (x [R, K], W [O, K]; the addends are optional)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, add_rows, add_cells, C):
+        x, W, bias, add_rows, add_cells = map(_c, (x, W, bias, add_rows, add_cells))
+        R, K = x.shape
+        O = W.shape[0]
+        y = x.new_empty((R, O))
+        call("smin_linear_rows_fwd", stream(), ptr(x), ptr(W), ptr(bias), ptr(add_rows), ptr(add_cells), C, R, O, K, ptr(y))
+        ctx.save_for_backward(x, W)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _c(dy)
+        R, K = x.shape
+        O = W.shape[0]
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dW = torch.empty_like(W)
+        dbias = x.new_empty((O,)) if need[2] else None
+        _, wp, wn = _ws(_lib.load().smin_linear_rows_bwd_workspace_bytes(R, O, K), x.device)
+        call("smin_linear_rows_bwd", stream(), ptr(dy), ptr(x), ptr(W.t().contiguous()), R, O, K, ptr(dx), ptr(dW), ptr(dbias), wp, wn)
+        dcells = None
+        if need[4]:
+            if ctx.C == 1:
+                dcells = dy
+            else:
+                dcells = x.new_empty((R // ctx.C, O))
+                call("smin_group_sum", stream(), ptr(dy), R // ctx.C, ctx.C, O, ptr(dcells))
+        return dx, dW, dbias, (dy if need[3] else None), dcells, None
 
 
 class GateFn(Function):

@@ -18,7 +18,8 @@ import torch
 import torch.nn as nn
 
 from .cells import CellLayout
-from .functional import BoundaryUnitFn, ContentUnitFn, GateFn, MomentUnitFn, ProposalMapFn, ScoreMapFn
+from .functional import (BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
+                         ProposalMapFn, ProposalMeansFn, ScoreMapFn)
 
 
 def _rows(mask):
@@ -41,6 +42,18 @@ class VideoEncoder(nn.Module):
         return self.ve(video_features) * vm + self.pe(pos).unsqueeze(0) * vm
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One auxiliary HIP stream per device for work that is independent of the main stream's chain."""
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
 class QueryEncoder(nn.Module):
     """reference models.py:38-64 (2-layer BiLSTM over packed word sequences)."""
 
@@ -48,13 +61,6 @@ class QueryEncoder(nn.Module):
         super().__init__()
         self.max_query_length, self.lstm_hidden_size = max_query_length, lstm_hidden_size
         self.lstm = nn.LSTM(input_size=300, hidden_size=lstm_hidden_size, num_layers=2, bidirectional=True, batch_first=True)
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device)
-            self._side = st
-        return st
 
     def forward(self, query_features, query_mask):
         """Same result as the reference's pack_padded_sequence / pad_packed_sequence round trip, but on padded
@@ -81,7 +87,7 @@ class QueryEncoder(nn.Module):
 
         # The two directions of a layer are independent chains of Nq tiny, latency-bound kernels: on the GPU they run
         # on two HIP streams side by side (autograd replays each chain's backward on the stream of its forward).
-        side = self._side_stream(x.device) if x.is_cuda else None
+        side = _side_stream(x.device) if x.is_cuda else None
         for layer in range(2):
             if side is None:
                 outs = [run(layer, "", x), run(layer, "_reverse", x)]
@@ -227,7 +233,8 @@ class ContentUnit(nn.Module):
         self.linear_c = nn.Linear(dl, D)
         self.attn_layer = ContentAttention(dl)
 
-    def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout, fcmean_in=None):
+    def word_operands(self, f_w, f_s, query_mask):
+        """Per-sample word-side operands of the attention core: (Mq, uq, what, shat, qmask rows)."""
         qm = _rows(query_mask)
         what = self.linear_w_hat(f_w) * qm.unsqueeze(-1)
         shat = self.linear_s_hat(f_s)
@@ -235,6 +242,10 @@ class ContentUnit(nn.Module):
         # W_q(c_hat) . kb^T == c_hat . (kb W_q.weight)^T + kb . W_q.bias : the per-cell dl x dl projection folds away
         Mq = torch.matmul(kb, self.attn_layer.W_q.weight)
         uq = torch.matmul(kb, self.attn_layer.W_q.bias)
+        return Mq, uq, what, shat, qm
+
+    def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout, fcmean_in=None):
+        Mq, uq, what, shat, qm = self.word_operands(f_w, f_s, query_mask)
         return ContentUnitFn.apply(fc, hbar, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
                                    self.linear_c.weight, self.linear_c.bias, layout, fcmean_in)
 
@@ -331,10 +342,57 @@ class SMIN(nn.Module):
         self.smis = nn.ModuleList([SMI(D, dl) for _ in range(num_smi_layers)])
         self.localization = Localization(D)
 
+    content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
+
+    def _forward_stream(self, f, fs, fw, query_mask, length_mask, layout):
+        """The same network with the content unit's two linear maps re-associated (exact in real arithmetic).
+
+        The unit output  f_c' = cc Wc^T + bc + f_c + hbar  (models.py:269-276) is consumed only by the next unit's
+        linear_c_hat (models.py:247) and, through its clip mean, by the moment unit (models.py:295); f_c itself starts
+        as clip means of f (models.py:117).  All of that is linear, so with g_k = f Wch_k^T
+            chat_k = clip_means(g_k) + sum_{l<k} cc_l (Wch_k Wc_l)^T + (sum_{l<k} hbar_l) Wch_k^T + const_k
+            mean_c f_c^k = mean_c f_c^{k-1} + (mean_c cc_k) Wc_k^T + bc_k + hbar_k
+        and the (N*C) x D tensors f_c never exist: every contraction over N*C rows is dl x dl instead of D x dl.
+        The parameter products (Wch_k Wc_l, Wch_k bc_l, g_k) are tiny and stay in torch, which also routes their
+        gradients back to the reference's parameters."""
+        T, L, C, dl = self.T, self.L, self.C, self.dl
+        N = layout.N
+        fm, fb = ProposalMeansFn.apply(f, layout, T, L, C)
+        # every layer's clip-mean term and constant in one pass over f
+        cus = [smi.content_unit for smi in self.smis]
+        consts, bsum = [], None
+        for cu in cus:
+            consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
+            bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
+        g_all = LinearRowsFn.apply(f.reshape(-1, self.D), torch.cat([cu.linear_c_hat.weight for cu in cus]), None, None, None, 1)
+        pgs = ClipWindowMeansFn.apply(g_all.view(f.shape[0], T, -1), torch.cat(consts), layout, T, L, C, len(cus))
+        cumean, H, hist = fm, None, []
+        for k, smi in enumerate(self.smis):
+            last = k == len(self.smis) - 1
+            cu = smi.content_unit
+            hbar_c, hbar_b, fm_res = GateFn.apply(fm, fs, layout)
+            Wch = cu.linear_c_hat.weight
+            chat = pgs[k]
+            if hist:
+                hp = LinearRowsFn.apply(H, Wch, None, None, None, 1)                 # (sum_l hbar_l) Wch^T, per cell
+                for n_l, (cc_l, Wc_l, _) in enumerate(hist):
+                    chat = LinearRowsFn.apply(cc_l, torch.matmul(Wch, Wc_l), None, chat, hp if n_l == 0 else None, C)
+            Mq, uq, what, shat, qm = cu.word_operands(fw, fs, query_mask)
+            cc, ccmean = ContentAttnFn.apply(chat, Mq, uq, what, shat, qm, layout, C, not last)
+            cumean = LinearRowsFn.apply(ccmean, cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1)
+            if not last:
+                H = hbar_c if H is None else H + hbar_c
+                hist.append((cc, cu.linear_c.weight, cu.linear_c.bias))
+            bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
+            fm, fb = smi.moment_unit.forward_packed(cumean, fm_res, bu, layout), bu
+        return self.localization.forward_packed(fm, fb, length_mask, layout)
+
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
         f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
         layout = pending.finish()                                  # the only host sync of a step; hidden behind the backbone
+        if self.content_stream and self.dl < self.D and 2 <= self.C <= 4 and layout.all_valid and f.is_cuda:
+            return self._forward_stream(f, fs, fw, query_mask, length_mask, layout)
         fc, fm, fb = self.pgm.forward_packed(f, layout)
         fcmean = fm                                                # mean_c fc: the map's f_m, then each layer's clip mean
         for k, smi in enumerate(self.smis):
