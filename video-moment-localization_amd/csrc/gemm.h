@@ -569,7 +569,7 @@ static inline int tn_splits(int Mrows, int I, int J)
     const int max_s = cdiv(Mrows, 256);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    if (s > 192) s = 192;
+    if (s > GEMM_SLOTS) s = GEMM_SLOTS;                 // single-tile outputs (dl x dl) still fill the chip
     return s;
 }
 

@@ -75,10 +75,11 @@ extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int N
 {
     (void)Nq;
     const size_t M = (size_t)N * C;
-    // content unit bwd: 2 x [M][dl] + TN slabs (<= 64 splits) + attention slabs + gate partials
-    size_t content = 3 * M * dl + 2 * M * 32 + 2 * (size_t)192 * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 512 * D;
-    // moment unit bwd: dX1 [N][D] + slabs [64][D][2D] + bias slabs
-    size_t moment = (size_t)N * D + (size_t)192 * ((size_t)D * 2 * D + D);
+    // content unit bwd: 2 x [M][dl] + TN slabs + attention slabs + gate partials
+    const size_t sp_c = (size_t)(M > 0 ? tn_splits((int)M, D, dl) + tn_splits((int)M, dl, D) : 2);
+    size_t content = 3 * M * dl + 2 * M * 32 + sp_c * ((size_t)D * dl + D + dl) + (size_t)B * 64 * ((size_t)64 * dl + dl + 32) + (size_t)B * 512 * D;
+    // moment unit bwd: dX1 [N][D] + TN slabs + bias slabs
+    size_t moment = (size_t)N * D + (size_t)(N > 0 ? tn_splits(N, D, 2 * D) : 1) * ((size_t)D * 2 * D + D);
     // boundary / score: per-row partials
     size_t other = (size_t)N + 8 * (size_t)B * 64 * D + (size_t)N * 4;
     // boundary unit bwd (L <= 64 assumed here; the host adds 2*B*L*L + 3*B*L*D for longer maps)
