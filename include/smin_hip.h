@@ -206,14 +206,16 @@ int smin_content_attn_bwd(void* stream, const float* dcc, const float* dccmean, 
                           const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                           float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, void* ws, size_t ws_bytes);
 
-/* y[r][:] = x[r][:] W^T + bias + add_rows[r][:] + add_cells[r / C][:]    x [R][K], W [O][K], y [R][O];
- * bias, add_rows, add_cells may be NULL.  Backward: dx = dy W (WT = W^T [K][O]; dx may be NULL), dW = dy^T x,
- * dbias = colsum(dy) (may be NULL); the gradient of add_rows is dy itself, of add_cells smin_group_sum(dy). */
-int smin_linear_rows_fwd(void* stream, const float* x, const float* W, const float* bias, const float* add_rows,
+/* y[r][:] = [x_0[r] | .. | x_{nseg-1}[r]] W^T + bias + add_rows[r][:] + add_cells[r / C][:]
+ * xs: HOST array of nseg <= 4 device pointers, x_s [R][K]; W [O][nseg*K]; y [R][O]; bias, add_rows, add_cells may
+ * be NULL.  Backward: dx_s = dy W_s (dxs: HOST array of nseg device pointers, or NULL; WT = W^T [nseg*K][O]),
+ * dW [O][nseg*K] = dy^T [x_0 | ..], dbias = colsum(dy) (may be NULL); the gradient of add_rows is dy itself, of
+ * add_cells smin_group_sum(dy). */
+int smin_linear_rows_fwd(void* stream, const float* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
                          const float* add_cells, int C, int R, int O, int K, float* y);
-size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int K);
-int smin_linear_rows_bwd(void* stream, const float* dy, const float* x, const float* WT, int R, int O, int K,
-                         float* dx, float* dW, float* dbias, void* ws, size_t ws_bytes);
+size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot);
+int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, int nseg, const float* WT, int R, int O, int K,
+                         float* const* dxs, float* dW, float* dbias, void* ws, size_t ws_bytes);
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
 int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 

@@ -45,9 +45,9 @@ SIGNATURES = {
     "smin_content_attn_fwd": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
     "smin_content_attn_bwd_workspace_bytes": [_i] * 4,
     "smin_content_attn_bwd": [_vp] * 6 + [_i] * 6 + [_vp] * 10 + [_vp, _sz],
-    "smin_linear_rows_fwd": [_vp] * 6 + [_i] * 4 + [_vp],
+    "smin_linear_rows_fwd": [_vp, _vp, _i] + [_vp] * 4 + [_i] * 4 + [_vp],
     "smin_linear_rows_bwd_workspace_bytes": [_i] * 3,
-    "smin_linear_rows_bwd": [_vp] * 4 + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
+    "smin_linear_rows_bwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
     "smin_group_sum": [_vp, _vp, _i, _i, _i, _vp],
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,

@@ -25,6 +25,31 @@ struct EpStoreRows {
     }
 };
 
+// up to four row-major [rows][w] matrices side by side along the contraction (or output) index
+struct CatMat {
+    const float* p[4]; int w;
+    struct Row { size_t off; };
+    struct Key {};
+    __device__ __forceinline__ Row row(int r) const { return Row{(size_t)r * w}; }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
+    __device__ __forceinline__ float4 at(const Row& r, int c) const {
+        const int sg = (c >= w) + (c >= 2 * w) + (c >= 3 * w);
+        const float* q = sg == 0 ? p[0] : sg == 1 ? p[1] : sg == 2 ? p[2] : p[3];
+        return ldg4(q + r.off + (c - sg * w));
+    }
+};
+struct EpSplitCols {                // column block s of the result goes to out[s] [rows][w]
+    float* out[4]; int w;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            const int sg = (col >= w) + (col >= 2 * w) + (col >= 3 * w);
+            float* q = sg == 0 ? out[0] : sg == 1 ? out[1] : sg == 2 ? out[2] : out[3];
+            stg4(q + (size_t)row * w + (col - sg * w), v);
+        });
+    }
+};
+
 // out[g][:] = sum_{c < C} x[g*C + c][:]
 __global__ void group_sum_kernel(const float* __restrict__ x, float* __restrict__ out, size_t groups, int C, int W4)
 {
@@ -40,43 +65,65 @@ __global__ void group_sum_kernel(const float* __restrict__ x, float* __restrict_
 
 using namespace smin;
 
-extern "C" int smin_linear_rows_fwd(void* stream, const float* x, const float* W, const float* bias, const float* add_rows,
+static CatMat cat_of(const float* const* xs, int nseg, int K)
+{
+    CatMat m;
+    for (int k = 0; k < 4; ++k) m.p[k] = xs[k < nseg ? k : 0];
+    m.w = K;
+    return m;
+}
+
+// y = [x_0 | .. | x_{nseg-1}] W^T + bias + add_rows + add_cells[r / C];  xs: HOST array of nseg <= 4 device pointers,
+// each x_s [R][K]; W [O][nseg*K].
+extern "C" int smin_linear_rows_fwd(void* stream, const float* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
                                     const float* add_cells, int C, int R, int O, int K, float* y)
 {
-    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1);
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1 && nseg >= 1 && nseg <= 4);
     if (R == 0) return 0;
-    return launch_gemm_nt((hipStream_t)stream, PlainMat{x, K}, PlainMat{W, K}, EpLinearRows{bias, add_rows, add_cells, C, y}, R, O, K);
+    const EpLinearRows ep{bias, add_rows, add_cells, C, y};
+    if (nseg == 1) return launch_gemm_nt((hipStream_t)stream, PlainMat{xs[0], K}, PlainMat{W, K}, ep, R, O, K);
+    return launch_gemm_nt((hipStream_t)stream, cat_of(xs, nseg, K), PlainMat{W, nseg * K}, ep, R, O, nseg * K);
 }
 
-extern "C" size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int K)
+extern "C" size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot)
 {
-    const int sp = R > 0 ? tn_splits(R, O, K) : 1;
-    return sizeof(float) * ((size_t)sp * O * K + (size_t)sp * O + 64);
+    const int sp = R > 0 ? tn_splits(R, O, Ktot) : 1;
+    return sizeof(float) * ((size_t)sp * O * Ktot + (size_t)sp * O + 64);
 }
 
-// dx = dy W (NULL to skip), dW = dy^T x, dbias = colsum(dy) (NULL to skip).  WT is W^T [K][O], row-major.
-extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* x, const float* WT, int R, int O, int K,
-                                    float* dx, float* dW, float* dbias, void* ws, size_t ws_bytes)
+// dx_s = dy W_s (dxs: HOST array of nseg device pointers, or NULL to skip), dW [O][nseg*K] = dy^T [x_0 | ..],
+// dbias = colsum(dy) (NULL to skip).  WT is W^T [nseg*K][O], row-major.
+extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, int nseg, const float* WT, int R, int O, int K,
+                                    float* const* dxs, float* dW, float* dbias, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
-    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0);
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && nseg >= 1 && nseg <= 4);
+    const int Kt = nseg * K;
     if (R == 0) {
-        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * K, st);
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * Kt, st);
         if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)O, st);
         return 0;
     }
-    SMIN_REQUIRE(ws_bytes >= smin_linear_rows_bwd_workspace_bytes(R, O, K));
+    SMIN_REQUIRE(ws_bytes >= smin_linear_rows_bwd_workspace_bytes(R, O, Kt));
     int rc;
-    if (dx) {
-        rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows{dx}, R, K, O);
+    if (dxs) {
+        if (nseg == 1) {
+            rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows{dxs[0]}, R, K, O);
+        } else {
+            EpSplitCols ep;
+            for (int k = 0; k < 4; ++k) ep.out[k] = dxs[k < nseg ? k : 0];
+            ep.w = K;
+            rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, ep, R, Kt, O);
+        }
         if (rc) return rc;
     }
-    const int sp = tn_splits(R, O, K);
+    const int sp = tn_splits(R, O, Kt);
     float* slab = reinterpret_cast<float*>(ws);
-    float* bslab = slab + (size_t)sp * O * K;
-    rc = launch_gemm_tn(st, PlainMat{dy, O}, PlainMat{x, K}, slab, bslab, R, O, K, sp);
+    float* bslab = slab + (size_t)sp * O * Kt;
+    if (nseg == 1) rc = launch_gemm_tn(st, PlainMat{dy, O}, PlainMat{xs[0], K}, slab, bslab, R, O, Kt, sp);
+    else rc = launch_gemm_tn(st, PlainMat{dy, O}, cat_of(xs, nseg, K), slab, bslab, R, O, Kt, sp);
     if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab, dW, O * K, sp); if (rc) return rc;
+    rc = launch_reduce_slabs(st, slab, dW, O * Kt, sp); if (rc) return rc;
     if (dbias) { rc = launch_reduce_slabs(st, bslab, dbias, O, sp); if (rc) return rc; }
     return 0;
 }

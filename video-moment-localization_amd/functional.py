@@ -195,40 +195,52 @@ class ContentAttnFn(Function):
         return dchat, dMq, duq, dwhat, dshat, None, None, None, None
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class LinearRowsFn(Function):
-    """y[r] = x[r] W^T + bias + add_rows[r] + add_cells[r // C]   (x [R, K], W [O, K]; the addends are optional)."""
+    """y[r] = [x_0[r] | x_1[r] | ..] W^T + bias + add_rows[r] + add_cells[r // C]
+    (each x_s [R, K], W [O, nseg*K]; bias and the addends are optional).  Call as
+    ``LinearRowsFn.apply(W, bias, add_rows, add_cells, C, x_0, x_1, ...)``."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, add_rows, add_cells, C):
-        x, W, bias, add_rows, add_cells = map(_c, (x, W, bias, add_rows, add_cells))
-        R, K = x.shape
+    def forward(ctx, W, bias, add_rows, add_cells, C, *xs):
+        W, bias, add_rows, add_cells = map(_c, (W, bias, add_rows, add_cells))
+        xs = tuple(_c(x) for x in xs)
+        R, K = xs[0].shape
         O = W.shape[0]
-        y = x.new_empty((R, O))
-        call("smin_linear_rows_fwd", stream(), ptr(x), ptr(W), ptr(bias), ptr(add_rows), ptr(add_cells), C, R, O, K, ptr(y))
-        ctx.save_for_backward(x, W)
+        y = xs[0].new_empty((R, O))
+        for x in xs:
+            ptr(x)                                                  # device / contiguity checks
+        call("smin_linear_rows_fwd", stream(), _ptr_array(xs), len(xs), ptr(W), ptr(bias), ptr(add_rows), ptr(add_cells), C, R, O, K, ptr(y))
+        ctx.save_for_backward(W, *xs)
         ctx.C = C
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        W, *xs = ctx.saved_tensors
         dy = _c(dy)
-        R, K = x.shape
-        O = W.shape[0]
+        R, K = xs[0].shape
+        O, nseg = W.shape[0], len(xs)
         need = ctx.needs_input_grad
-        dx = torch.empty_like(x) if need[0] else None
+        want_dx = any(need[5:])
+        dxs = [torch.empty_like(x) for x in xs] if want_dx else None
         dW = torch.empty_like(W)
-        dbias = x.new_empty((O,)) if need[2] else None
-        _, wp, wn = _ws(_lib.load().smin_linear_rows_bwd_workspace_bytes(R, O, K), x.device)
-        call("smin_linear_rows_bwd", stream(), ptr(dy), ptr(x), ptr(W.t().contiguous()), R, O, K, ptr(dx), ptr(dW), ptr(dbias), wp, wn)
+        dbias = dy.new_empty((O,)) if need[1] else None
+        _, wp, wn = _ws(_lib.load().smin_linear_rows_bwd_workspace_bytes(R, O, nseg * K), dy.device)
+        call("smin_linear_rows_bwd", stream(), ptr(dy), _ptr_array(xs), nseg, ptr(W.t().contiguous()), R, O, K,
+             _ptr_array(dxs) if want_dx else None, ptr(dW), ptr(dbias), wp, wn)
         dcells = None
-        if need[4]:
+        if need[3]:
             if ctx.C == 1:
                 dcells = dy
             else:
-                dcells = x.new_empty((R // ctx.C, O))
+                dcells = dy.new_empty((R // ctx.C, O))
                 call("smin_group_sum", stream(), ptr(dy), R // ctx.C, ctx.C, O, ptr(dcells))
-        return dx, dW, dbias, (dy if need[3] else None), dcells, None
+        return (dW, dbias, (dy if need[2] else None), dcells, None) + (tuple(dxs) if want_dx else (None,) * nseg)
 
 
 class GateFn(Function):

@@ -364,7 +364,7 @@ class SMIN(nn.Module):
         for cu in cus:
             consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
             bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
-        g_all = LinearRowsFn.apply(f.reshape(-1, self.D), torch.cat([cu.linear_c_hat.weight for cu in cus]), None, None, None, 1)
+        g_all = LinearRowsFn.apply(torch.cat([cu.linear_c_hat.weight for cu in cus]), None, None, None, 1, f.reshape(-1, self.D))
         pgs = ClipWindowMeansFn.apply(g_all.view(f.shape[0], T, -1), torch.cat(consts), layout, T, L, C, len(cus))
         cumean, H, hist = fm, None, []
         for k, smi in enumerate(self.smis):
@@ -373,13 +373,14 @@ class SMIN(nn.Module):
             hbar_c, hbar_b, fm_res = GateFn.apply(fm, fs, layout)
             Wch = cu.linear_c_hat.weight
             chat = pgs[k]
-            if hist:
-                hp = LinearRowsFn.apply(H, Wch, None, None, None, 1)                 # (sum_l hbar_l) Wch^T, per cell
-                for n_l, (cc_l, Wc_l, _) in enumerate(hist):
-                    chat = LinearRowsFn.apply(cc_l, torch.matmul(Wch, Wc_l), None, chat, hp if n_l == 0 else None, C)
+            for lo in range(0, len(hist), 4):                              # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
+                part = hist[lo:lo + 4]
+                hp = LinearRowsFn.apply(Wch, None, None, None, 1, H) if lo == 0 else None   # (sum_l hbar_l) Wch^T, per cell
+                chat = LinearRowsFn.apply(torch.cat([torch.matmul(Wch, Wc_l) for _, Wc_l, _ in part], dim=1), None, chat, hp, C,
+                                          *[cc_l for cc_l, _, _ in part])
             Mq, uq, what, shat, qm = cu.word_operands(fw, fs, query_mask)
             cc, ccmean = ContentAttnFn.apply(chat, Mq, uq, what, shat, qm, layout, C, not last)
-            cumean = LinearRowsFn.apply(ccmean, cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1)
+            cumean = LinearRowsFn.apply(cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1, ccmean)
             if not last:
                 H = hbar_c if H is None else H + hbar_c
                 hist.append((cc, cu.linear_c.weight, cu.linear_c.bias))
