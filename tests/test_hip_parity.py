@@ -350,3 +350,108 @@ def test_c_abi_layout_helpers_and_boundary_reduce(dev):
     call("smin_boundary_reduce_bwd", stream(), ptr(dy), ptr(Ab), ptr(hbar), ptr(lay.cells), ptr(lay.row_ptr), lay.N, B, L, D, ptr(dAb), ptr(dh))
     assert (dAb - (dy.unsqueeze(2) * hd).sum(-1) * mm).abs().max().item() < 1e-4
     assert (dh - lay.pack(Ab.unsqueeze(-1) * dy.unsqueeze(2))).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------- content stream: pieces and whole
+def test_clip_event_table_matches_content_matrix(dev):
+    """The clip-boundary table is the sparsity pattern of the reference's content matrix: integrating its +-1/cs
+    entries over time must give back compute_content_matrix (golden g4_wc, produced from the reference) exactly."""
+    import models
+    from vml_amd.functional import clip_event_table
+    z = H.load_npz("g4_wc")
+    for key in [k[6:] for k in z.files if k.startswith("start/")]:
+        T, L, C = (int(v) for v in key.split("_"))
+        size = torch.from_numpy(z["size/" + key]).long()
+        start = torch.from_numpy(z["start/" + key]).long()
+        val = torch.from_numpy(z["val/" + key])
+        t = torch.arange(T)
+        Wc = ((t >= start.unsqueeze(-1)) & (t < (start + size).unsqueeze(-1))).float() * val.unsqueeze(-1)   # (L, L, C, T)
+        off, tab = (x.cpu() for x in clip_event_table(dev, T, L, C))
+        diff = torch.zeros(L, L, C, T + 1)
+        nclip = (size > 0).sum(-1)                                           # clips present per cell
+        for tt in range(T):
+            e = tab[off[tt]:off[tt + 1]]
+            key_, sc = e[:, 0], e[:, 1].contiguous().view(torch.float32)
+            i, j, c, wm = key_ >> 18, (key_ >> 6) & 4095, key_ & 7, (key_ >> 3) & 1
+            diff[i.long(), j.long(), c.long(), tt] += sc
+            # the mean-path flag marks the first clip's start and the last clip's end of a cell
+            want = torch.where(sc > 0, c == 0, c + 1 == nclip[i.long(), j.long()])
+            assert torch.equal(wm.bool(), want), key
+        assert torch.equal(diff.cumsum(-1)[..., :T], Wc), key
+
+
+@pytest.mark.parametrize("R,O,K,nseg,C", [(1000, 128, 128, 1, 4), (515, 64, 32, 2, 1), (2048, 512, 128, 1, 1), (999, 128, 128, 3, 3), (64, 24, 16, 4, 2)])
+def test_linear_rows_forward_backward(dev, R, O, K, nseg, C):
+    from vml_amd.functional import LinearRowsFn
+    g = torch.Generator().manual_seed(R + O + K)
+    R = (R // C) * C
+    xs = [torch.randn(R, K, generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(nseg)]
+    W = torch.randn(O, nseg * K, generator=g, dtype=torch.float64).requires_grad_(True)
+    bias = torch.randn(O, generator=g, dtype=torch.float64).requires_grad_(True)
+    ar = torch.randn(R, O, generator=g, dtype=torch.float64).requires_grad_(True)
+    ac = torch.randn(R // C, O, generator=g, dtype=torch.float64).requires_grad_(True)
+    ref = torch.cat(xs, 1) @ W.t() + bias + ar + ac.repeat_interleave(C, 0)
+    dy = torch.randn(R, O, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    leaves = [W, bias, ar, ac] + xs
+    got_in = [t.detach().float().to(dev).requires_grad_(True) for t in leaves]
+    y = LinearRowsFn.apply(got_in[0], got_in[1], got_in[2], got_in[3], C, *got_in[4:])
+    tol = 4e-6 * (nseg * K) ** 0.5 * 8
+    assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= tol
+    y.backward(dy.float().to(dev))
+    for a, b in zip(got_in, leaves):
+        scale = max(1.0, b.grad.abs().max().item())
+        assert (a.grad.cpu().double() - b.grad).abs().max().item() <= 2e-5 * scale, tuple(b.shape)
+
+
+def test_clip_window_means_forward_backward(dev):
+    """Clip means of a projected frame feature, one tensor per segment, against the dense content-matrix einsum
+    (models.py:117) and its autograd gradient."""
+    import models
+    from vml_amd.functional import ClipWindowMeansFn
+    g = torch.Generator().manual_seed(5)
+    for (T, L, C, W, nseg, B) in [(32, 8, 4, 16, 3, 3), (16, 16, 4, 8, 2, 2), (24, 12, 3, 24, 1, 2)]:
+        lm = torch.zeros(B, L, dtype=torch.bool)
+        for b in range(B):
+            lm[b, : L - 2 * b] = True
+        mm = torch.triu(lm.unsqueeze(2) & lm.unsqueeze(1))
+        lay = models.vml_amd.CellLayout.from_mask(mm.to(dev))
+        gfeat = torch.randn(B, T, nseg * W, generator=g, dtype=torch.float64).requires_grad_(True)
+        bias = torch.randn(nseg * W, generator=g, dtype=torch.float64).requires_grad_(True)
+        Wc = models.compute_content_matrix(T, L, C).double()
+        dense = torch.einsum("ijct,btd->bijcd", Wc, gfeat) + bias                     # (B, L, L, C, nseg*W)
+        rows = dense[mm]                                                              # (N, C, nseg*W), sorted by (b, i, j)
+        refs = [rows[..., s * W:(s + 1) * W].reshape(-1, W) for s in range(nseg)]
+        dys = [torch.randn(r.shape, generator=g, dtype=torch.float64) for r in refs]
+        sum((r * d).sum() for r, d in zip(refs, dys)).backward()
+        gi = gfeat.detach().float().to(dev).requires_grad_(True)
+        bi = bias.detach().float().to(dev).requires_grad_(True)
+        outs = ClipWindowMeansFn.apply(gi, bi, lay, T, L, C, nseg)
+        for o, r in zip(outs, refs):
+            assert (o.detach().cpu().double() - r.detach()).abs().max().item() < 2e-6
+        sum((o * d.float().to(dev)).sum() for o, d in zip(outs, dys)).backward()
+        assert (gi.grad.cpu().double() - gfeat.grad).abs().max().item() < 2e-5 * max(1.0, gfeat.grad.abs().max().item())
+        assert (bi.grad.cpu().double() - bias.grad).abs().max().item() < 2e-5 * max(1.0, bias.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["g1_r4", "g2_r2_ragged"])
+def test_content_stream_equals_unit_as_written(dev, name):
+    """SMIN with the content unit re-associated into the dl-dimensional space (content stream) against the same model
+    running every unit as the reference writes it: scores, loss and every parameter gradient."""
+    from vml_amd import loss_fn
+    cfg, sd, batch, out, grads, loss_ref = H.split_tiny(H.load_npz(name))
+    b = {k: v.to(dev) for k, v in batch.items()}
+    res = []
+    for stream_on in (True, False):
+        m = build_model(cfg, sd, dev)
+        m.content_stream = stream_on
+        pm, ps, pe, pa = m(*H.model_inputs(b))
+        loss = loss_fn(pm, b["ym"], b["sm"], b["moment_mask"], ps, b["ys"], b["ss"], pe, b["ye"], b["se"], pa, b["ya"], b["length_mask"])
+        loss.backward()
+        res.append(((pm, ps, pe, pa), loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    for a, c in zip(res[0][0], res[1][0]):
+        assert (a - c).abs().max().item() < 5e-6
+    assert abs(res[0][1] - res[1][1]) < 5e-6
+    for k in res[0][2]:
+        ga, gc = res[0][2][k], res[1][2][k]
+        assert (ga - gc).abs().max().item() <= 5e-4 * gc.abs().max().item() + 1e-7, k
