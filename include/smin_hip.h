@@ -143,7 +143,8 @@ int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, con
  * d mu / d fm is the identity and is left to the caller (dfm += dmu). */
 int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                          const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
-                         float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes);
+                         float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
+                         int all_valid /* 1: every listed cell has m == 1 (mask-driven list): skips the mask lookups */);
 
 /* ---- Localization.forward (models.py:335-344): score heads.
  *   pm [B][L][L] dense, zero-filled outside the cell list;  wb [3][D], bb [3] = (ps, pe, pa) heads;

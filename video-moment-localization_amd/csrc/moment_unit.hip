@@ -67,7 +67,7 @@ extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const flo
 
 extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                                     const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
-                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes)
+                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
@@ -79,10 +79,19 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
     SMIN_REQUIRE((size_t)((bslab + (size_t)sp * D) - w) * sizeof(float) <= ws_bytes);
     if (N > 0) {
         // dX = (m * dmu) @ Wcat        [N, 2D], contraction over D
-        int rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
-        if (rc) return rc;
         // dWcat[D, 2D] = (m * dmu)^T @ X ; dbcat = colsum(m * dmu)
-        rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+        // all_valid (mask-driven cell list, m == 1 everywhere): dmu is read as a plain matrix, without the per-row
+        // mask lookups the operand loads would otherwise wait for
+        int rc;
+        if (all_valid) {
+            rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
+            if (rc) return rc;
+            rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+        } else {
+            rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
+            if (rc) return rc;
+            rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+        }
         if (rc) return rc;
         rc = launch_reduce_slabs(st, slab, dWcat, D * 2 * D, sp); if (rc) return rc;
         rc = launch_reduce_slabs(st, bslab, dbcat, D, sp); if (rc) return rc;
