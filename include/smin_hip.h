@@ -220,6 +220,20 @@ int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, 
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
 int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 
+/* ---- QueryEncoder's bidirectional LSTM layer (models.py:38-64: nn.LSTM over a packed, padded batch), one layer per
+ * call, both directions.  X [B*Nq][In]; Wih_cat [8H][In] = [W_ih; W_ih_reverse]; bias_cat [8H] = b_ih + b_hh per
+ * direction; W4 [2][H][H][4] with W4[d][k][u][g] = W_hh_d[g*H+u][k]; len [B] valid lengths (device).  Outputs: Hout
+ * [B][Nq][2H] (zero at padded positions, as pad_packed_sequence gives), and for backward G [B][Nq][2][4H] (gate
+ * activations i,f,g,o) and Cs [B][Nq][2][H] (cell states).  Requires In % 4 == 0, H % 4 == 0, H <= 256. */
+int smin_bilstm_layer_fwd(void* stream, const float* X, const float* Wih_cat, const float* bias_cat, const float* W4,
+                          const int32_t* len, int B, int Nq, int In, int H, float* G, float* Hout, float* Cs);
+size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H);
+/* dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H] (= d b_ih = d b_hh),
+ * dWhh [2][4H][H].  Wih_catT [In][8H]; Wr4 [2][H][H][4] with Wr4[d][jj][u][r] = W_hh_d[4*jj+r][u]. */
+int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
+                          const float* Wih_catT, const float* Wr4, const int32_t* len, int B, int Nq, int In, int H,
+                          float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
+
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);

@@ -1,0 +1,274 @@
+// Bidirectional LSTM layer of the query encoder (reference models.py:38-64: nn.LSTM(300, H, num_layers=2,
+// bidirectional, batch_first) over pack_padded_sequence / pad_packed_sequence), forward and backward.
+//
+// The library path (MIOpen through torch) issues ~8 launches per time step and direction -- ~600 launches per train
+// step, each a few microseconds of work, so the host cannot keep the GPU fed (4.3 ms of wall time per step for 0.3 ms
+// of arithmetic).  Here one launch runs the whole recurrence of a layer, both directions:
+//   * the input projections of all time steps and both directions are one GEMM on the MFMA engine (gemm.h);
+//   * the recurrence is split over the batch (samples are independent), never over hidden units, so no workgroup
+//     ever waits for another: grid = (ceil(B / 4), 2 directions), 4 threads per hidden unit (a quarter of the
+//     contraction each, 4 waves per SIMD hide the weight stream's latency).  W_hh (1 MB at H = 256) is re-streamed
+//     from L2 every step by every workgroup; h lives in LDS, c in registers;
+//   * sequence lengths are honoured in-kernel: the forward direction stops at len_b, the reverse direction starts at
+//     position len_b - 1, padded positions are written as zeros -- exactly the packed-sequence result, without
+//     gathers, masks or a host copy of the lengths.
+// Backward: one launch for the recurrence of the gate gradients, then the weight gradients as GEMMs over all
+// (sample, position) rows.
+#include "gemm.h"
+#include "smin_hip.h"
+
+namespace smin {
+
+constexpr int LSTM_BS = 4;          // samples per workgroup
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct EpBiasRows {
+    const float* bias; float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            stg4(out + (size_t)row * N + col, f4add(v, ldg4(bias + col)));
+        });
+    }
+};
+struct EpStoreLstm {
+    float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+    }
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Thread roles (H <= 256, Hp = H rounded up to 64, 4*Hp threads): in the contraction phase thread (kq, u) sums its
+// quarter of the contraction index for unit u and all LSTM_BS samples (one float4 of W per step of the loop: the four
+// gates of unit u, so the weight stream is 16-byte loads coalesced over u); the partial sums meet in LDS and thread
+// (b, u) = (kq, u) finishes sample b -- the cell state of (b, u) lives in that thread's registers for the whole launch.
+//
+// G    [B][Nq][2][4H]  in: input projections + biases (gate order i, f, g, o); out: the gate activations
+// W4   [2][H][H][4]    W4[d][k][u][g] = W_hh_d[g*H + u][k]
+// Hout [B][Nq][2H]     Cs [B][Nq][2][H]
+__global__ __launch_bounds__(1024)
+void bilstm_fwd_kernel(float* __restrict__ G, const float* __restrict__ W4, const int* __restrict__ len, int B, int Nq, int H,
+                       float* __restrict__ Hout, float* __restrict__ Cs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BS = LSTM_BS;
+    const int Hp = blockDim.x >> 2;
+    float* hs = lds;                                               // [H][BS]
+    float* part = lds + (size_t)H * BS;                            // [4 kq][4 g][BS][Hp]
+    const int d = blockIdx.y, b0 = blockIdx.x * BS, u = threadIdx.x % Hp, kq = threadIdx.x / Hp;
+    const bool own = u < H;
+    const int uu = own ? u : 0, H4 = 4 * H, kn = H / 4, k0 = kq * kn;
+    const int bme = b0 + kq;                                       // the sample this thread finishes
+    const int L = bme < B ? min(len[bme], Nq) : 0;
+    float c = 0.f;
+    if (kq == 0 && own) *reinterpret_cast<float4*>(hs + u * BS) = f4zero();
+    __syncthreads();
+    const float4* w = reinterpret_cast<const float4*>(W4) + ((size_t)d * H + k0) * H + uu;
+    for (int s = 0; s < Nq; ++s) {
+        const bool act = s < L;
+        const int p = d == 0 ? s : L - 1 - s;
+        const size_t row = (size_t)bme * Nq + (act ? p : 0);
+        float gx[4];
+        {
+            const float* g = G + (row * 2 + d) * H4 + uu;
+            const bool ld = act && own;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gx[q] = ld ? g[q * H] : 0.f;
+        }
+        f32x2 a[BS][2];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) { a[b][0] = f32x2{0.f, 0.f}; a[b][1] = f32x2{0.f, 0.f}; }
+#pragma unroll 16
+        for (int k = 0; k < kn; ++k) {
+            const float4 h4 = *reinterpret_cast<const float4*>(hs + (k0 + k) * BS);
+            const float4 w4 = w[(size_t)k * H];
+            const f32x2 w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int b = 0; b < BS; ++b) {
+                const f32x2 hb = {hv[b], hv[b]};
+                a[b][0] = __builtin_elementwise_fma(hb, w01, a[b][0]);
+                a[b][1] = __builtin_elementwise_fma(hb, w23, a[b][1]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            part[((kq * 4 + 0) * BS + b) * Hp + u] = a[b][0].x; part[((kq * 4 + 1) * BS + b) * Hp + u] = a[b][0].y;
+            part[((kq * 4 + 2) * BS + b) * Hp + u] = a[b][1].x; part[((kq * 4 + 3) * BS + b) * Hp + u] = a[b][1].y;
+        }
+        __syncthreads();                                            // partial sums visible; everyone is done reading hs
+        if (own && bme < B) {
+            if (act) {
+                float z[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    z[q] = gx[q] + ((part[((0 * 4 + q) * BS + kq) * Hp + u] + part[((1 * 4 + q) * BS + kq) * Hp + u]) +
+                                    (part[((2 * 4 + q) * BS + kq) * Hp + u] + part[((3 * 4 + q) * BS + kq) * Hp + u]));
+                const float ig = sigm(z[0]), fg = sigm(z[1]), gg = tanhf(z[2]), og = sigm(z[3]);
+                c = fmaf(fg, c, ig * gg);
+                const float hn = og * tanhf(c);
+                float* g = G + (row * 2 + d) * H4 + u;
+                g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+                Cs[(row * 2 + d) * H + u] = c;
+                Hout[row * 2 * H + d * H + u] = hn;
+                hs[u * BS + kq] = hn;
+            } else {
+                Hout[((size_t)bme * Nq + s) * 2 * H + d * H + u] = 0.f;            // padded position s >= len
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dG [B][Nq][2][4H] = gradient of the pre-activation gates (zero at padded positions)
+// Wr4 [2][H][H][4]   Wr4[d][jj][u][r] = W_hh_d[4*jj + r][u]
+__global__ __launch_bounds__(1024)
+void bilstm_bwd_kernel(const float* __restrict__ dHout, const float* __restrict__ G, const float* __restrict__ Cs,
+                       const float* __restrict__ Wr4, const int* __restrict__ len, int B, int Nq, int H, float* __restrict__ dG)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BS = LSTM_BS;
+    const int Hp = blockDim.x >> 2;
+    float* dgs = lds;                                              // [4H][BS]
+    float* part = lds + (size_t)4 * H * BS;                        // [4 jq][BS][Hp]
+    const int d = blockIdx.y, b0 = blockIdx.x * BS, u = threadIdx.x % Hp, jq = threadIdx.x / Hp;
+    const bool own = u < H;
+    const int uu = own ? u : 0, H4 = 4 * H, jn = H / 4, j0 = jq * jn;   // this thread contracts rows 4*j0 .. 4*(j0+jn) of W_hh
+    const int bme = b0 + jq;
+    const int L = bme < B ? min(len[bme], Nq) : 0;
+    float dhn = 0.f, dcn = 0.f;
+    const float4* w = reinterpret_cast<const float4*>(Wr4) + ((size_t)d * H + j0) * H + uu;
+    for (int s = Nq - 1; s >= 0; --s) {
+        const bool act = s < L;
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (own && bme < B) {
+            if (act) {
+                const int p = d == 0 ? s : L - 1 - s;
+                const size_t row = (size_t)bme * Nq + p;
+                const float* g = G + (row * 2 + d) * H4 + u;
+                const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+                const float ct = Cs[(row * 2 + d) * H + u];
+                const float cp = s > 0 ? Cs[(((size_t)bme * Nq + (d == 0 ? p - 1 : p + 1)) * 2 + d) * H + u] : 0.f;
+                const float dh = dHout[row * 2 * H + d * H + u] + dhn;
+                const float tc = tanhf(ct);
+                const float dc = fmaf(dh * og, 1.0f - tc * tc, dcn);
+                dg[0] = dc * gg * ig * (1.0f - ig);
+                dg[1] = dc * cp * fg * (1.0f - fg);
+                dg[2] = dc * ig * (1.0f - gg * gg);
+                dg[3] = dh * tc * og * (1.0f - og);
+                dcn = dc * fg;
+                float* o = dG + (row * 2 + d) * H4 + u;
+                o[0] = dg[0]; o[H] = dg[1]; o[2 * H] = dg[2]; o[3 * H] = dg[3];
+            } else {
+                float* o = dG + ((((size_t)bme * Nq + s) * 2 + d) * H4) + u;       // padded position s >= len
+                o[0] = 0.f; o[H] = 0.f; o[2 * H] = 0.f; o[3 * H] = 0.f;
+            }
+        }
+        if (own) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dgs[(size_t)(q * H + u) * BS + jq] = dg[q];
+        }
+        __syncthreads();
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 8
+        for (int j = 0; j < jn; ++j) {
+            const float4 w4 = w[(size_t)j * H];
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 g4 = *reinterpret_cast<const float4*>(dgs + (size_t)(4 * (j0 + j) + r) * BS);
+                const f32x2 ww = {wv[r], wv[r]};
+                a01 = __builtin_elementwise_fma(f32x2{g4.x, g4.y}, ww, a01);
+                a23 = __builtin_elementwise_fma(f32x2{g4.z, g4.w}, ww, a23);
+            }
+        }
+        part[(jq * BS + 0) * Hp + u] = a01.x; part[(jq * BS + 1) * Hp + u] = a01.y;
+        part[(jq * BS + 2) * Hp + u] = a23.x; part[(jq * BS + 3) * Hp + u] = a23.y;
+        __syncthreads();
+        if (act) dhn = (part[(0 * BS + jq) * Hp + u] + part[(1 * BS + jq) * Hp + u]) + (part[(2 * BS + jq) * Hp + u] + part[(3 * BS + jq) * Hp + u]);
+        // no third barrier: dgs is rewritten only after every thread has passed the barrier above (its reads are over),
+        // and part only after the next step's first barrier, which every thread reaches after the reads of this line
+    }
+}
+
+// Hprev[d][b][p][:] = h of direction d one step before position p: Hout[b][p-1][0:H] (d = 0), Hout[b][p+1][H:2H] (d = 1)
+__global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int Nq, int H, float* __restrict__ Hprev)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = (size_t)2 * B * Nq * H;
+    if (idx >= tot) return;
+    const int u = (int)(idx % H);
+    const size_t r = idx / H;
+    const int p = (int)(r % Nq);
+    const size_t bd = r / Nq;
+    const int b = (int)(bd % B), d = (int)(bd / B);
+    const int q = d == 0 ? p - 1 : p + 1;
+    Hprev[idx] = (q >= 0 && q < Nq) ? Hout[((size_t)b * Nq + q) * 2 * H + d * H + u] : 0.f;
+}
+
+}  // namespace smin
+
+using namespace smin;
+
+extern "C" int smin_bilstm_layer_fwd(void* stream, const float* X, const float* Wih_cat, const float* bias_cat, const float* W4,
+                                     const int32_t* len, int B, int Nq, int In, int H, float* G, float* Hout, float* Cs)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(In % 4 == 0 && H % 4 == 0 && H >= 4 && H <= 256 && B >= 1 && Nq >= 1);
+    int rc = launch_gemm_nt(st, PlainMat{X, In}, PlainMat{Wih_cat, In}, EpBiasRows{bias_cat, G}, B * Nq, 8 * H, In);
+    if (rc) return rc;
+    const int Hp = cdiv(H, 64) * 64;
+    const size_t lds = sizeof(float) * ((size_t)H * LSTM_BS + (size_t)16 * LSTM_BS * Hp);
+    hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, G, W4, len, B, Nq, H, Hout, Cs);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H)
+{
+    const int R = B * Nq;
+    const size_t sp1 = (size_t)tn_splits(R, 8 * H, In), sp2 = (size_t)tn_splits(R, 4 * H, H);
+    return sizeof(float) * ((size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + sp2 * (size_t)4 * H * H + 256);
+}
+
+// dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H]
+extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
+                                     const float* Wih_catT, const float* Wr4, const int32_t* len, int B, int Nq, int In, int H,
+                                     float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(In % 4 == 0 && H % 4 == 0 && H >= 4 && H <= 256 && B >= 1 && Nq >= 1);
+    SMIN_REQUIRE(ws_bytes >= smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, H));
+    const int R = B * Nq, H4 = 4 * H, H8 = 8 * H;
+    float* w = reinterpret_cast<float*>(ws);
+    float* dG = w;
+    float* Hprev = dG + (size_t)R * H8;
+    float* slab = Hprev + (size_t)2 * R * H;
+    const int Hp = cdiv(H, 64) * 64;
+    const size_t lds = sizeof(float) * ((size_t)H4 * LSTM_BS + (size_t)4 * LSTM_BS * Hp);
+    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Wr4, len, B, Nq, H, dG);
+    SMIN_LAUNCH_CHECK();
+    int rc;
+    if (dX) {
+        rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
+        if (rc) return rc;
+    }
+    const int sp1 = tn_splits(R, H8, In);
+    float* bslab = slab + (size_t)sp1 * H8 * In;
+    rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
+    rc = launch_reduce_slabs(st, slab, dWih_cat, H8 * In, sp1); if (rc) return rc;
+    rc = launch_reduce_slabs(st, bslab, dbias_cat, H8, sp1); if (rc) return rc;
+    const size_t tot = (size_t)2 * R * H;
+    hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev);
+    SMIN_LAUNCH_CHECK();
+    const int sp2 = tn_splits(R, H4, H);
+    float* slab2 = bslab + (size_t)sp1 * H8;
+    for (int d = 0; d < 2; ++d) {
+        rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, PlainMat{Hprev + (size_t)d * R * H, H}, slab2, (float*)nullptr, R, H4, H, sp2);
+        if (rc) return rc;
+        rc = launch_reduce_slabs(st, slab2, dWhh + (size_t)d * H4 * H, H4 * H, sp2); if (rc) return rc;
+    }
+    return 0;
+}

@@ -243,6 +243,43 @@ class LinearRowsFn(Function):
         return (dW, dbias, (dy if need[2] else None), dcells, None) + (tuple(dxs) if want_dx else (None,) * nseg)
 
 
+class BiLstmLayerFn(Function):
+    """One bidirectional LSTM layer over a padded batch with per-sample lengths (reference models.py:46-58: nn.LSTM on
+    pack_padded_sequence / pad_packed_sequence).  x [B, Nq, In], length int32 [B] (device) -> [B, Nq, 2H], zero at
+    padded positions.  Parameter order as nn.LSTM names them: (w_ih, w_hh, b_ih, b_hh) forward, then reverse."""
+
+    @staticmethod
+    def forward(ctx, x, length, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        x = _c(x)
+        B, Nq, In = x.shape
+        H = w_hh_f.shape[1]
+        Wih = torch.cat([w_ih_f, w_ih_r]).contiguous()                       # [8H, In]
+        bias = torch.cat([b_ih_f + b_hh_f, b_ih_r + b_hh_r]).contiguous()   # [8H]
+        Whh = torch.stack([w_hh_f, w_hh_r]).contiguous()                    # [2, 4H, H]
+        W4 = Whh.view(2, 4, H, H).permute(0, 3, 2, 1).contiguous()          # [2, k, u, gate]
+        G = x.new_empty((B, Nq, 2, 4 * H))
+        Hout = x.new_empty((B, Nq, 2 * H))
+        Cs = x.new_empty((B, Nq, 2, H))
+        call("smin_bilstm_layer_fwd", stream(), ptr(x), ptr(Wih), ptr(bias), ptr(W4), ptr(length), B, Nq, In, H, ptr(G), ptr(Hout), ptr(Cs))
+        ctx.save_for_backward(x, length, Hout, G, Cs, Wih, Whh)
+        return Hout
+
+    @staticmethod
+    def backward(ctx, dH):
+        x, length, Hout, G, Cs, Wih, Whh = ctx.saved_tensors
+        B, Nq, In = x.shape
+        H = Whh.shape[2]
+        dH = _c(dH)
+        dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dWih, dbias, dWhh = torch.empty_like(Wih), x.new_empty((8 * H,)), torch.empty_like(Whh)
+        _, wp, wn = _ws(_lib.load().smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, H), x.device)
+        Wr4 = Whh.view(2, H, 4, H).permute(0, 1, 3, 2).contiguous()         # [2, row // 4, u, row % 4]
+        call("smin_bilstm_layer_bwd", stream(), ptr(dH), ptr(x), ptr(Hout), ptr(G), ptr(Cs), ptr(Wih.t().contiguous()), ptr(Wr4), ptr(length),
+             B, Nq, In, H, ptr(dX), ptr(dWih), ptr(dbias), ptr(dWhh), wp, wn)
+        H4 = 4 * H
+        return (dX, None, dWih[:H4], dWhh[0], dbias[:H4], dbias[:H4], dWih[H4:], dWhh[1], dbias[H4:], dbias[H4:])
+
+
 class GateFn(Function):
     """hbar = sigmoid(fm * fs) * fm -- the gated moment feature of models.py:191 and 272-274, computed once per layer.
 

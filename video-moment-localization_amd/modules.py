@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .cells import CellLayout
-from .functional import (BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
+from .functional import (BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
                          ProposalMapFn, ProposalMeansFn, ScoreMapFn)
 
 
@@ -57,6 +57,8 @@ def _side_stream(device):
 class QueryEncoder(nn.Module):
     """reference models.py:38-64 (2-layer BiLSTM over packed word sequences)."""
 
+    fused_lstm = True              # HIP BiLSTM layer kernels on the GPU (False: torch / MIOpen, same results)
+
     def __init__(self, max_query_length=13, lstm_hidden_size=256):
         super().__init__()
         self.max_query_length, self.lstm_hidden_size = max_query_length, lstm_hidden_size
@@ -71,6 +73,14 @@ class QueryEncoder(nn.Module):
         B, Nq, _ = query_features.shape
         H = self.lstm_hidden_size
         length = query_mask.reshape(B, -1).sum(1).long()
+        if query_features.is_cuda and self.fused_lstm and H <= 256 and H % 4 == 0:
+            # one HIP launch per layer runs the whole recurrence, both directions, lengths honoured in-kernel
+            # (bilstm.hip): the library path below is ~600 launches of a few microseconds each per train step
+            x, len32 = query_features, length.to(torch.int32)
+            for layer in range(2):
+                w = [getattr(self.lstm, f"{n}_l{layer}{sfx}") for sfx in ("", "_reverse") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                x = BiLstmLayerFn.apply(x, len32, *w)
+            return self._heads(x, length, B, Nq, H)
         t = torch.arange(Nq, device=query_features.device).unsqueeze(0)
         valid = (t < length.unsqueeze(1)).to(query_features.dtype).unsqueeze(-1)          # (B, Nq, 1)
         rev = (length.unsqueeze(1) - 1 - t).clamp(min=0).unsqueeze(-1)                     # (B, Nq, 1)
@@ -103,6 +113,10 @@ class QueryEncoder(nn.Module):
                 y_rev.record_stream(cur)
                 outs = [y_fwd, y_rev]
             x = torch.cat(outs, dim=2)
+        return self._heads(x, length, B, Nq, H)
+
+    def _heads(self, x, length, B, Nq, H):
+        """(f_s, f_w) of models.py:56-63 from the padded layer output."""
         fw = x
         if Nq < self.max_query_length:
             fw = torch.nn.functional.pad(fw, (0, 0, 0, self.max_query_length - Nq))
