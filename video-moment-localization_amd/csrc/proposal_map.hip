@@ -14,17 +14,44 @@ namespace smin {
 
 struct double4_ { double x, y, z, w; };
 
-// Pf[b][t][d] = sum_{t' < t} f[b][t'][d], t = 0..T
-__global__ void time_prefix_kernel(const float* __restrict__ f, double* __restrict__ Pf, int B, int T, int D)
+// Blocked running sum over time for both directions of the proposal map (forward: the fp64 prefix Pf of f; backward:
+// df = running sum of the event array E).  A serial form keeps one thread per (b, d) busy for T dependent
+// steps (130 us at T = 256 with half the CUs idle); here a 1024-thread workgroup owns 64 feature columns of a sample
+// and cuts time into 16 segments: per-segment sums, a 16-entry exclusive scan through LDS, then the segment's running
+// sums (the second read hits L2).  fp64 accumulation throughout; the order of additions is fixed.
+template <bool PREFIX>
+__global__ __launch_bounds__(1024)
+void time_scan_kernel(const float* __restrict__ in, const float* __restrict__ dfb, int T, int L, int D,
+                      double* __restrict__ Pf, float* __restrict__ df)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * D) return;
-    const int b = idx / D, d = idx % D;
-    const float* src = f + (size_t)b * T * D + d;
-    double* dst = Pf + (size_t)b * (T + 1) * D + d;
+    __shared__ double part[16][64];
+    const int col = threadIdx.x & 63, seg = threadIdx.x >> 6, b = blockIdx.y;
+    const int d = blockIdx.x * 64 + col;
+    const bool ok = d < D;
+    const int TL = (T + 15) / 16, ta = min(T, seg * TL), tb = min(T, ta + TL);
+    const float* src = in + (size_t)b * T * D + (ok ? d : 0);
+    double local = 0.0;
+    for (int t = ta; t < tb; ++t) local += (double)src[(size_t)t * D];
+    part[seg][col] = local;
+    __syncthreads();
     double run = 0.0;
-    dst[0] = 0.0;
-    for (int t = 0; t < T; ++t) { run += (double)src[(size_t)t * D]; dst[(size_t)(t + 1) * D] = run; }
+    for (int k = 0; k < seg; ++k) run += part[k][col];
+    if (!ok) return;
+    if (PREFIX) {
+        double* dst = Pf + (size_t)b * (T + 1) * D + d;
+        for (int t = ta; t < tb; ++t) { dst[(size_t)t * D] = run; run += (double)src[(size_t)t * D]; }
+        if (tb == T && ta < T) dst[(size_t)T * D] = run;
+        if (T == 0 && seg == 0) dst[0] = 0.0;
+    } else {
+        const int r = T / L;
+        const float fr = (float)r;
+        for (int t = ta; t < tb; ++t) {
+            run += (double)src[(size_t)t * D];
+            float v = (float)run;
+            if (dfb && t / r < L) v += dfb[((size_t)b * L + t / r) * D + d] / fr;
+            df[((size_t)b * T + t) * D + d] = v;
+        }
+    }
 }
 
 // one 128-thread workgroup per cell
@@ -344,7 +371,7 @@ extern "C" int smin_proposal_map_fwd(void* stream, const float* f, const int32_t
     SMIN_REQUIRE(D <= 2048);
     SMIN_REQUIRE(ws_bytes >= sizeof(double) * (size_t)B * (T + 1) * D);
     double* Pf = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(time_prefix_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, f, Pf, B, T, D);
+    hipLaunchKernelGGL((time_scan_kernel<true>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, f, (const float*)nullptr, T, L, D, Pf, (float*)nullptr);
     SMIN_LAUNCH_CHECK();
     if (N > 0 && (fc || fm)) {
         hipLaunchKernelGGL(proposal_map_fwd_kernel, dim3(N), dim3(128), 0, st, Pf, cells, T, L, C, D, fc, fm);
@@ -429,7 +456,8 @@ extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float
             SMIN_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, dfb, B, T, L, D, df);
+    if (E) hipLaunchKernelGGL((time_scan_kernel<false>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, E, dfb, T, L, D, (double*)nullptr, df);
+    else hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, dfb, B, T, L, D, df);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
@@ -475,7 +503,7 @@ extern "C" int smin_clip_window_means_fwd(void* stream, const float* g, const fl
     SMIN_REQUIRE(ws_bytes >= sizeof(double) * (size_t)B * (T + 1) * D);
     if (N == 0) return 0;
     double* Pf = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(time_prefix_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, g, Pf, B, T, D);
+    hipLaunchKernelGGL((time_scan_kernel<true>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, g, (const float*)nullptr, T, L, D, Pf, (float*)nullptr);
     SMIN_LAUNCH_CHECK();
     const size_t rows = (size_t)N * C, tot = rows * (W / 4) * nseg;
     hipLaunchKernelGGL(clip_window_means_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Pf, bias, cells, T, L, C, W, nseg, rows, out);
@@ -508,7 +536,8 @@ extern "C" int smin_clip_window_means_bwd(void* stream, const float* const* dout
             SMIN_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, (const float*)nullptr, B, T, L, D, dg);
+    if (E) hipLaunchKernelGGL((time_scan_kernel<false>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, E, (const float*)nullptr, T, L, D, (double*)nullptr, dg);
+    else hipLaunchKernelGGL(proposal_map_bwd_scan_kernel, dim3(cdiv(B * D, 128)), dim3(128), 0, st, E, (const float*)nullptr, B, T, L, D, dg);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
