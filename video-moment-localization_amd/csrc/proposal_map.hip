@@ -71,14 +71,17 @@ void proposal_map_fwd_kernel(const double* __restrict__ Pf, const int* __restric
     const double* P = Pf + (size_t)cl.b * (T + 1) * D;
     for (int d = threadIdx.x * 4; d < D; d += 512) {
         float4 sum = f4zero();
+        // consecutive clips share a boundary row of the prefix: nclip + 1 row reads instead of 2 * nclip
+        const double* pb = P + (size_t)(cl.i * r) * D + d;
+        double4_ lo = {pb[0], pb[1], pb[2], pb[3]};
         for (int c = 0; c < C; ++c) {
             float4 v = f4zero();
             if (c < nclip) {
-                const int s = cl.i * r + c * cs;
-                const double* ps = P + (size_t)s * D + d;
-                const double* pe = P + (size_t)(s + cs) * D + d;
-                v.x = (float)((pe[0] - ps[0]) * inv); v.y = (float)((pe[1] - ps[1]) * inv);
-                v.z = (float)((pe[2] - ps[2]) * inv); v.w = (float)((pe[3] - ps[3]) * inv);
+                const double* pe = pb + (size_t)((c + 1) * cs) * D;
+                const double4_ hi = {pe[0], pe[1], pe[2], pe[3]};
+                v.x = (float)((hi.x - lo.x) * inv); v.y = (float)((hi.y - lo.y) * inv);
+                v.z = (float)((hi.z - lo.z) * inv); v.w = (float)((hi.w - lo.w) * inv);
+                lo = hi;
             }
             if (fc) stg4(fc + ((size_t)n * C + c) * D + d, v);
             sum = f4add(sum, v);
@@ -467,30 +470,35 @@ extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float
 //   out[s][n*C + c][:] = m * (mean_{t in clip c of cell n} g[b][t][s*W : (s+1)*W] + bias[s*W : (s+1)*W])
 // With g = f [Wch_1; ..; Wch_k]^T this is every layer's linear_c_hat applied to ProposalGeneration's f_c without ever
 // forming f_c (content stream).  Backward: smin_clip_window_means_bwd.
-__global__ void clip_window_means_kernel(const double* __restrict__ Pf, const float* __restrict__ bias, const int* __restrict__ cells,
-                                         int T, int L, int C, int W, int nseg, size_t rows, float* __restrict__ out)
+__global__ __launch_bounds__(128)
+void clip_window_means_kernel(const double* __restrict__ Pf, const float* __restrict__ bias, const int* __restrict__ cells,
+                              int T, int L, int C, int W, int nseg, size_t rows, float* __restrict__ out)
 {
-    const int W4 = W / 4, D = W * nseg;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * W4 * nseg) return;
-    const int d4 = (int)(idx % W4);
-    const size_t row = (idx / W4) % rows;
-    const int sg = (int)(idx / ((size_t)W4 * rows));
-    const size_t n = row / C; const int c = (int)(row % C);
+    // one workgroup per cell; a thread owns float4 columns of the nseg*W features and walks the cell's clips along the
+    // shared boundary rows of the prefix
+    const int n = blockIdx.x, D = W * nseg;
     const Cell cl = load_cell(cells, n);
     const int r = T / L, w = cl.j - cl.i + 1, nf = w * r, cs = max(1, nf / C);
     const int nclip = (cl.m != 0 && w >= 1) ? min(C, nf) : 0;
-    const int d = sg * W + d4 * 4;
-    float4 v = f4zero();
-    if (c < nclip) {
-        const double inv = (double)(1.0f / (float)cs);
-        const int s0 = cl.i * r + c * cs;
-        const double* ps = Pf + ((size_t)cl.b * (T + 1) + s0) * D + d;
-        const double* pe = ps + (size_t)cs * D;
-        v = make_float4((float)((pe[0] - ps[0]) * inv), (float)((pe[1] - ps[1]) * inv), (float)((pe[2] - ps[2]) * inv), (float)((pe[3] - ps[3]) * inv));
+    const double inv = (double)(1.0f / (float)cs);
+    for (int d = threadIdx.x * 4; d < D; d += 512) {
+        const int sg = d / W, dw = d - sg * W;
+        const float4 b4 = (bias && cl.m != 0) ? ldg4(bias + d) : f4zero();
+        const double* pb = Pf + ((size_t)cl.b * (T + 1) + cl.i * r) * D + d;
+        double4_ lo = {pb[0], pb[1], pb[2], pb[3]};
+        float* o = out + ((size_t)sg * rows + (size_t)n * C) * W + dw;
+        for (int c = 0; c < C; ++c) {
+            float4 v = b4;
+            if (c < nclip) {
+                const double* pe = pb + (size_t)((c + 1) * cs) * D;
+                const double4_ hi = {pe[0], pe[1], pe[2], pe[3]};
+                v = f4add(v, make_float4((float)((hi.x - lo.x) * inv), (float)((hi.y - lo.y) * inv),
+                                         (float)((hi.z - lo.z) * inv), (float)((hi.w - lo.w) * inv)));
+                lo = hi;
+            }
+            stg4(o + (size_t)c * W, v);
+        }
     }
-    if (bias && cl.m != 0) v = f4add(v, ldg4(bias + d));
-    stg4(out + ((size_t)sg * rows + row) * W + d4 * 4, v);
 }
 
 
@@ -505,8 +513,8 @@ extern "C" int smin_clip_window_means_fwd(void* stream, const float* g, const fl
     double* Pf = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL((time_scan_kernel<true>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, g, (const float*)nullptr, T, L, D, Pf, (float*)nullptr);
     SMIN_LAUNCH_CHECK();
-    const size_t rows = (size_t)N * C, tot = rows * (W / 4) * nseg;
-    hipLaunchKernelGGL(clip_window_means_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Pf, bias, cells, T, L, C, W, nseg, rows, out);
+    const size_t rows = (size_t)N * C;
+    hipLaunchKernelGGL(clip_window_means_kernel, dim3(N), dim3(128), 0, st, Pf, bias, cells, T, L, C, W, nseg, rows, out);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
