@@ -66,10 +66,11 @@ int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, cons
 
 /* ---- Gated moment feature shared by ContentUnit (models.py:272-274) and BoundaryUnit (models.py:191):
  *   hbar[n,:] = sigmoid(f_m[n,:] * f_s[b,:]) * f_m[n,:]          hbar [N][D]
- * backward: dfm [N][D], dfs [B][D] from dhbar (the sum of both consumers' gradients). */
+ * backward: dfm [N][D], dfs [B][D].  hbar and f_m usually have several consumers (content unit, boundary unit, the
+ * content stream's running sum; f_m also passes through to the moment unit's residual): dhbar / dres are HOST arrays of
+ * n_dhbar (1..4) / n_dres (0..4) device pointers [N][D] whose sum is the gradient of hbar / is added to dfm. */
 int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar);
-int smin_gate_bwd(void* stream, const float* dhbar, const float* dhbar2 /* nullable: second consumer */,
-                  const float* dres /* nullable: gradient of the pass-through copy of fm, added to dfm */,
+int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhbar, const float* const* dres, int n_dres,
                   const float* fm, const float* fs, const int32_t* row_ptr,
                   int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes);
 
@@ -144,7 +145,8 @@ int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, con
 int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                          const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                          float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
-                         int all_valid /* 1: every listed cell has m == 1 (mask-driven list): skips the mask lookups */);
+                         int all_valid /* 1: every listed cell has m == 1 (mask-driven list): skips the mask lookups */,
+                         const float* dfcmean_acc /* nullable [N][D]: added into dfcmean (a second consumer of fcmean) */);
 
 /* ---- Localization.forward (models.py:335-344): score heads.
  *   pm [B][L][L] dense, zero-filled outside the cell list;  wb [3][D], bb [3] = (ps, pe, pa) heads;

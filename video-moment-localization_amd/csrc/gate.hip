@@ -22,9 +22,18 @@ __global__ void gate_fwd_kernel(const float* __restrict__ fm, const float* __res
 
 // dfm = dh * (g + fm*g*(1-g)*fs) ; partial[b][chunk][:] = sum over the chunk's cells of dh * fm^2 * g*(1-g)
 // grid (chunks, B), 128 threads, float4 columns.
+struct GradList { const float* p[4]; int n; };   // up to four gradient tensors of one value, summed on the fly
+
+__device__ __forceinline__ float4 grad_sum(const GradList& g, size_t off) {
+    float4 v = ldg4(g.p[0] + off);
+    if (g.n > 1) v = f4add(v, ldg4(g.p[1] + off));
+    if (g.n > 2) v = f4add(v, ldg4(g.p[2] + off));
+    if (g.n > 3) v = f4add(v, ldg4(g.p[3] + off));
+    return v;
+}
+
 __global__ __launch_bounds__(128)
-void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dres,
-                     const float* __restrict__ fm, const float* __restrict__ fs,
+void gate_bwd_kernel(GradList dh, GradList dres, const float* __restrict__ fm, const float* __restrict__ fs,
                      const int* __restrict__ row_ptr, int L, int D, int cells_per_chunk, int max_chunks,
                      float* __restrict__ dfm, float* __restrict__ partial)
 {
@@ -37,9 +46,9 @@ void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2
         const float4 s4 = ldg4(fs + (size_t)b * D + d);
         float4 acc = f4zero();
         for (int n = n_begin; n < n_end; ++n) {
-            float4 ds = ldg4(dh + (size_t)n * D + d);
-            if (dh2) ds = f4add(ds, ldg4(dh2 + (size_t)n * D + d));       // second consumer of hbar (summed here, not by autograd)
-            const float4 x = ldg4(fm + (size_t)n * D + d);
+            const size_t off = (size_t)n * D + d;
+            const float4 ds = grad_sum(dh, off);                    // every consumer of hbar (summed here, not by autograd)
+            const float4 x = ldg4(fm + off);
             float4 o;
 #define GATE1(F)                                                                  \
             {                                                                     \
@@ -50,8 +59,8 @@ void gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2
             }
             GATE1(x) GATE1(y) GATE1(z) GATE1(w)
 #undef GATE1
-            if (dres) o = f4add(o, ldg4(dres + (size_t)n * D + d));         // gradient of the pass-through copy of f_m
-            stg4(dfm + (size_t)n * D + d, o);
+            if (dres.n > 0) o = f4add(o, grad_sum(dres, off));      // gradients of the pass-through copies of f_m
+            stg4(dfm + off, o);
         }
         stg4(partial + ((size_t)b * max_chunks + chunk) * D + d, acc);
     }
@@ -84,17 +93,20 @@ extern "C" int smin_gate_fwd(void* stream, const float* fm, const float* fs, con
     return 0;
 }
 
-extern "C" int smin_gate_bwd(void* stream, const float* dhbar, const float* dhbar2, const float* dres,
+extern "C" int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhbar, const float* const* dres, int n_dres,
                              const float* fm, const float* fs, const int32_t* row_ptr,
                              int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes)
 {
     (void)N;
     hipStream_t st = (hipStream_t)stream;
-    SMIN_REQUIRE(D % 4 == 0);
+    SMIN_REQUIRE(D % 4 == 0 && n_dhbar >= 1 && n_dhbar <= 4 && n_dres >= 0 && n_dres <= 4);
     int cpc, mc; chunking_fine(L, &cpc, &mc);
     SMIN_REQUIRE(ws_bytes >= sizeof(float) * (size_t)B * mc * D);
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, dhbar, dhbar2, dres, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
+    GradList gh, gr;
+    for (int k = 0; k < 4; ++k) { gh.p[k] = dhbar[k < n_dhbar ? k : 0]; gr.p[k] = n_dres > 0 ? dres[k < n_dres ? k : 0] : nullptr; }
+    gh.n = n_dhbar; gr.n = n_dres;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, gh, gr, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_partial_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, partial, row_ptr, L, D, cpc, mc, dfs);
     SMIN_LAUNCH_CHECK();

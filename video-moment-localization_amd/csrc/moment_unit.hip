@@ -17,12 +17,13 @@ struct EpMomentOut {                // mu = (acc + bcat) * m + fm
     }
 };
 
-struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean
-    float* dx1; float* dmean; int D;
+struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean (+ acc: another
+    float* dx1; float* dmean; int D; const float* acc;       //  consumer's gradient of fcmean, summed here)
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
         chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
-            float* dst = col < D ? dx1 + col : dmean + (col - D);
-            stg4(dst + (size_t)row * D, v);
+            if (col < D) { stg4(dx1 + (size_t)row * D + col, v); return; }
+            const size_t o = (size_t)row * D + (col - D);
+            stg4(dmean + o, acc ? f4add(v, ldg4(acc + o)) : v);
         });
     }
 };
@@ -67,7 +68,8 @@ extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const flo
 
 extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                                     const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
-                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid)
+                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
+                                    const float* dfcmean_acc)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
@@ -84,11 +86,11 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
         // mask lookups the operand loads would otherwise wait for
         int rc;
         if (all_valid) {
-            rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
+            rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
             if (rc) return rc;
             rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
         } else {
-            rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D}, N, 2 * D, D);
+            rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
             if (rc) return rc;
             rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
         }

@@ -283,35 +283,36 @@ class BiLstmLayerFn(Function):
 class GateFn(Function):
     """hbar = sigmoid(fm * fs) * fm -- the gated moment feature of models.py:191 and 272-274, computed once per layer.
 
-    Returns (hbar for the content unit, the same hbar for the boundary unit, fm passed through for the moment unit's
-    residual).  The three outputs share storage pairwise; handing them out separately lets the one backward kernel
-    sum their gradients instead of autograd doing it in two extra full-size passes per layer."""
+    Returns n_hbar views of hbar followed by n_res views of fm (defaults: hbar for the content unit, hbar for the
+    boundary unit, fm passed through for the moment unit's residual).  Handing every consumer its own view lets the
+    one backward kernel sum their gradients instead of autograd doing it in extra full-size passes."""
 
     @staticmethod
-    def forward(ctx, fm, fs, layout):
+    def forward(ctx, fm, fs, layout, n_hbar=2, n_res=1):
         fm, fs = _c(fm), _c(fs)
         N, D = fm.shape
         hbar = torch.empty_like(fm)
         call("smin_gate_fwd", stream(), ptr(fm), ptr(fs), ptr(layout.cells), N, D, ptr(hbar))
         ctx.save_for_backward(fm, fs)
-        ctx.layout = layout
-        return hbar, hbar.view_as(hbar), fm.view_as(fm)
+        ctx.layout, ctx.n_hbar = layout, n_hbar
+        return (hbar,) + tuple(hbar.view_as(hbar) for _ in range(n_hbar - 1)) + tuple(fm.view_as(fm) for _ in range(n_res))
 
     @staticmethod
-    def backward(ctx, dh1, dh2, dres):
+    def backward(ctx, *grads):
         fm, fs = ctx.saved_tensors
         layout = ctx.layout
         N, D = fm.shape
-        dh1, dh2, dres = _c(dh1), _c(dh2), _c(dres)
-        if dh1 is None:
-            dh1, dh2 = dh2, None
-        if dh1 is None:
-            dh1 = torch.zeros_like(fm)
+        dh = [_c(g) for g in grads[:ctx.n_hbar] if g is not None]
+        dr = [_c(g) for g in grads[ctx.n_hbar:] if g is not None]
+        if not dh:
+            dh = [torch.zeros_like(fm)]
+        for g in dh + dr:
+            ptr(g)
         dfm, dfs = torch.empty_like(fm), torch.empty_like(fs)
         _, wp, wn = _ws(4 * layout.B * 512 * D + 4096, fm.device)
-        call("smin_gate_bwd", stream(), ptr(dh1), ptr(dh2), ptr(dres), ptr(fm), ptr(fs), ptr(layout.row_ptr), N, layout.B, layout.L, D,
-             ptr(dfm), ptr(dfs), wp, wn)
-        return dfm, dfs, None
+        call("smin_gate_bwd", stream(), _ptr_array(dh), len(dh), _ptr_array(dr) if dr else None, len(dr), ptr(fm), ptr(fs),
+             ptr(layout.row_ptr), N, layout.B, layout.L, D, ptr(dfm), ptr(dfs), wp, wn)
+        return dfm, dfs, None, None, None
 
 
 class ContentUnitFn(Function):
@@ -412,6 +413,8 @@ class MomentUnitFn(Function):
 
     @staticmethod
     def forward(ctx, fcmean, fm, fb, Wcat, bcat, layout):
+        """Returns (mu, view of fcmean): a later consumer of fcmean (the content stream's clip-mean chain) should read
+        the view, so that its gradient is summed into dfcmean by the backward epilogue instead of by autograd."""
         fcmean, fm, fb, Wcat, bcat = map(_c, (fcmean, fm, fb, Wcat, bcat))
         N, D = fm.shape
         B, L, _ = fb.shape
@@ -419,21 +422,23 @@ class MomentUnitFn(Function):
         _timed_call("moment_unit_fwd", "smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu))
         ctx.save_for_backward(fcmean, fb, Wcat)
         ctx.layout = layout
-        return mu
+        return mu, fcmean.view_as(fcmean)
 
     @staticmethod
-    def backward(ctx, dmu):
+    def backward(ctx, dmu, dacc):
         fcmean, fb, Wcat = ctx.saved_tensors
         layout = ctx.layout
         N, D = fcmean.shape
         B, L, _ = fb.shape
-        dmu = _c(dmu)
+        dmu, dacc = _c(dmu), _c(dacc)
+        if dmu is None:
+            dmu = torch.zeros_like(fcmean)
         WcatT = Wcat.t().contiguous()
         dfcmean, dfb = torch.empty_like(fcmean), torch.empty_like(fb)
         dWcat, dbcat = torch.empty_like(Wcat), fb.new_empty((D,))
         _, wp, wn = _unit_ws(layout, 4, D, 4, 1, fb.device)
         call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcmean), ptr(fb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
-             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid))
+             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid), ptr(dacc))
         return dfcmean, dmu, dfb, dWcat, dbcat, None
 
 

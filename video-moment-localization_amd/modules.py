@@ -279,11 +279,18 @@ class MomentUnit(nn.Module):
         self.conv_layer_fb = nn.Conv2d(D, D, 1)
         self.conv_layer_fc = nn.Conv2d(D, D, 1)
 
-    def forward_packed(self, fcmean, fm, f_b, layout):
+    def forward_stream(self, fcmean, fm, f_b, layout):
+        """(mu, view of fcmean for the next consumer of the clip-mean chain)"""
         D = self.D
         Wcat = torch.cat([self.conv_layer_fb.weight.view(D, D), self.conv_layer_fc.weight.view(D, D)], dim=1)
         bcat = self.conv_layer_fb.bias + self.conv_layer_fc.bias
         return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)
+
+    def forward_packed(self, fcmean, fm, f_b, layout):
+        D = self.D
+        Wcat = torch.cat([self.conv_layer_fb.weight.view(D, D), self.conv_layer_fc.weight.view(D, D)], dim=1)
+        bcat = self.conv_layer_fb.bias + self.conv_layer_fc.bias
+        return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)[0]
 
     def forward(self, f_c, f_m, f_b, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
@@ -380,11 +387,18 @@ class SMIN(nn.Module):
             bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
         g_all = LinearRowsFn.apply(torch.cat([cu.linear_c_hat.weight for cu in cus]), None, None, None, 1, f.reshape(-1, self.D))
         pgs = ClipWindowMeansFn.apply(g_all.view(f.shape[0], T, -1), torch.cat(consts), layout, T, L, C, len(cus))
-        cumean, H, hist = fm, None, []
+        cumean, H, hist = None, None, []
+        nl = len(self.smis)
         for k, smi in enumerate(self.smis):
-            last = k == len(self.smis) - 1
+            last = k == nl - 1
             cu = smi.content_unit
-            hbar_c, hbar_b, fm_res = GateFn.apply(fm, fs, layout)
+            # every consumer of hbar / fm gets its own view, so the gate's backward kernel sums their gradients:
+            # hbar: content stream (clip-mean chain), boundary unit, [the next layer's gate term, the running sum]
+            n_hbar = 2 if last else (3 if k > 0 or nl < 3 else 4)
+            views = GateFn.apply(fm, fs, layout, n_hbar, 2 if k == 0 else 1)
+            hbar_c, hbar_b, fm_res = views[0], views[1], views[n_hbar]
+            if k == 0:
+                cumean = views[n_hbar + 1]                                   # mean_c f_c of the proposal map is f_m
             Wch = cu.linear_c_hat.weight
             chat = pgs[k]
             for lo in range(0, len(hist), 4):                              # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
@@ -396,10 +410,16 @@ class SMIN(nn.Module):
             cc, ccmean = ContentAttnFn.apply(chat, Mq, uq, what, shat, qm, layout, C, not last)
             cumean = LinearRowsFn.apply(cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1, ccmean)
             if not last:
-                H = hbar_c if H is None else H + hbar_c
+                if H is None:
+                    H = views[2]                                             # read by the next layer's gate term
+                    Hsum = views[3] if n_hbar > 3 else views[2]              # and by the running sum after that
+                else:
+                    H = Hsum + views[2]
+                    Hsum = H
                 hist.append((cc, cu.linear_c.weight, cu.linear_c.bias))
             bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
-            fm, fb = smi.moment_unit.forward_packed(cumean, fm_res, bu, layout), bu
+            fm, cumean = smi.moment_unit.forward_stream(cumean, fm_res, bu, layout)
+            fb = bu
         return self.localization.forward_packed(fm, fb, length_mask, layout)
 
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
