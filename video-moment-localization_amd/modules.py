@@ -399,6 +399,13 @@ class SMIN(nn.Module):
             hbar_c, hbar_b, fm_res = views[0], views[1], views[n_hbar]
             if k == 0:
                 cumean = views[n_hbar + 1]                                   # mean_c f_c of the proposal map is f_m
+            # The boundary unit reads only the layer inputs: a chain of small, latency-bound launches that runs on a
+            # second HIP stream beside the content stream (whose attention kernels leave most of a CU's registers and
+            # LDS free) and joins before the moment unit; autograd replays its backward on the same stream.
+            cur, side = torch.cuda.current_stream(fm.device), _side_stream(fm.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
             Wch = cu.linear_c_hat.weight
             chat = pgs[k]
             for lo in range(0, len(hist), 4):                              # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
@@ -417,7 +424,8 @@ class SMIN(nn.Module):
                     H = Hsum + views[2]
                     Hsum = H
                 hist.append((cc, cu.linear_c.weight, cu.linear_c.bias))
-            bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
+            cur.wait_stream(side)
+            bu.record_stream(cur)
             fm, cumean = smi.moment_unit.forward_stream(cumean, fm_res, bu, layout)
             fb = bu
         return self.localization.forward_packed(fm, fb, length_mask, layout)
