@@ -135,6 +135,8 @@ def main():
         B = args.batch
     torch.manual_seed(43)                                    # config/*.yml: seed 43, default initialisation
     model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
+    if os.environ.get("SMIN_NO_OVERLAP"):
+        model.overlap_boundary = False
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
     net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)

@@ -14,8 +14,12 @@ def env_world():
 def init(backend=None, device=None):
     """Initialise the default process group from the torchrun environment (MASTER_ADDR should be 127.0.0.1)."""
     world, rank, _ = env_world()
-    if world == 1 or dist.is_initialized():
+    if (world == 1 and not os.environ.get("SMIN_FORCE_DDP")) or dist.is_initialized():
         return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -38,7 +42,7 @@ def shard_batch(batch, rank, world):
 def wrap(model, device=None, bucket_cap_mb=8):
     """DistributedDataParallel with small buckets so the all-reduce overlaps the backward kernels
     (28-36 MB of fp32 gradients per step: SURVEY 5)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("SMIN_FORCE_DDP")):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None

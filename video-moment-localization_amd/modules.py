@@ -364,6 +364,7 @@ class SMIN(nn.Module):
         self.localization = Localization(D)
 
     content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
+    overlap_boundary = True        # boundary unit on a second HIP stream beside the content stream
 
     def _forward_stream(self, f, fs, fw, query_mask, length_mask, layout):
         """The same network with the content unit's two linear maps re-associated (exact in real arithmetic).
@@ -402,7 +403,8 @@ class SMIN(nn.Module):
             # The boundary unit reads only the layer inputs: a chain of small, latency-bound launches that runs on a
             # second HIP stream beside the content stream (whose attention kernels leave most of a CU's registers and
             # LDS free) and joins before the moment unit; autograd replays its backward on the same stream.
-            cur, side = torch.cuda.current_stream(fm.device), _side_stream(fm.device)
+            cur = torch.cuda.current_stream(fm.device)
+            side = _side_stream(fm.device) if self.overlap_boundary else cur
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
