@@ -152,3 +152,27 @@ def test_loss_and_metric_restatements_match_oracle_and_golden():
     for k, v in zip(z["keys"], z["vals"]):
         assert got[str(k)] == float(v)
     assert got == O.compute_ious(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))
+
+
+def test_batch_targets_match_per_sample_restatement():
+    """build_targets (device-side, batched) against the per-sample restatement of dataset.py:95-155.
+    PARITY UNPINNED: dataset.py is not importable here (torchtext / h5py absent) and the reference ships no fixtures
+    for these functions; oracle/labels_oracle.py follows its source text line by line."""
+    import models
+    from oracle import labels_oracle as LO
+    g = torch.Generator().manual_seed(3)
+    for (T, L, B) in [(256, 64, 7), (128, 64, 5), (64, 16, 6), (16, 16, 3)]:
+        dur = torch.rand(B, generator=g) * 200 + 5
+        ts = torch.rand(B, generator=g) * dur * 0.6
+        te = ts + torch.rand(B, generator=g) * (dur - ts) * 0.9 + 0.5
+        nf = torch.randint(3, 2 * T, (B,), generator=g)
+        out = models.vml_amd.build_targets(torch.stack([ts, te], 1), dur, nf, T, L)
+        assert out["video_mask"].dtype == torch.uint8 and out["video_mask"].shape == (B, T, 1)
+        for b in range(B):
+            ref = LO.sample_targets(float(ts[b]), float(te[b]), float(dur[b]), int(nf[b]), T, L)
+            for k, v in ref.items():
+                a = out[k][b]
+                if v.dtype.is_floating_point:
+                    assert torch.allclose(a, v, rtol=2e-6, atol=1e-7, equal_nan=True), (T, L, b, k)
+                else:
+                    assert torch.equal(a.to(v.dtype).reshape(v.shape), v), (T, L, b, k)

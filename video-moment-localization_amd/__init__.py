@@ -16,3 +16,4 @@ from .modules import (  # noqa: F401
     MomentUnit, ProposalGeneration, QueryEncoder, VideoEncoder, compute_content_matrix,
 )
 from .training import loss_fn, loss_fn_torch, bce_loss, compute_ious  # noqa: F401
+from .labels import build_targets  # noqa: F401
