@@ -185,7 +185,7 @@ def main():
                 traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<PairMeanMat,PlainMat,EpMomentOut> (moment-unit forward)",
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<CatMat,PlainMat,EpMomentOut> (moment-unit forward)",
                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": len(durs),
                     "flops_per_launch": flops, "valid_cells_per_launch": n_valid}

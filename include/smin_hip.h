@@ -139,14 +139,19 @@ int smin_boundary_unit_bwd(void* stream, const float* dout, const float* fb, con
  *   mu[n,:] = m * ( [fb[b,i]*fb[b,j] | fcmean[n]] @ Wcat^T + bcat ) + fm[n,:]
  * Wcat [D][2D] = [conv_layer_fb.weight | conv_layer_fc.weight], bcat [D] = sum of the two biases. */
 int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
-                         int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu);
+                         int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu,
+                         const float* x1 /* nullable [N][D] = f_b[i]*f_b[j] from smin_pair_product: the contraction then
+                                            reads two plain matrices (pass it to smin_moment_unit_bwd as well) */);
+/* x1[n][:] = f_b[b][i][:] * f_b[b][j][:]  -- the pair half of the moment unit's left operand (models.py:292-294) */
+int smin_pair_product(void* stream, const float* fb, const int32_t* cells, int N, int L, int D, float* x1);
 /* WcatT [2D][D].  dfcmean [N][D], dfb [B][L][D], dWcat [D][2D], dbcat [D]; the residual gradient
  * d mu / d fm is the identity and is left to the caller (dfm += dmu). */
 int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                          const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                          float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
                          int all_valid /* 1: every listed cell has m == 1 (mask-driven list): skips the mask lookups */,
-                         const float* dfcmean_acc /* nullable [N][D]: added into dfcmean (a second consumer of fcmean) */);
+                         const float* dfcmean_acc /* nullable [N][D]: added into dfcmean (a second consumer of fcmean) */,
+                         const float* x1 /* nullable: the pair product saved by smin_moment_unit_fwd */);
 
 /* ---- Localization.forward (models.py:335-344): score heads.
  *   pm [B][L][L] dense, zero-filled outside the cell list;  wb [3][D], bb [3] = (ps, pe, pa) heads;

@@ -25,20 +25,6 @@ struct EpStoreRows {
     }
 };
 
-// up to four row-major [rows][w] matrices side by side along the contraction (or output) index
-struct CatMat {
-    const float* p[4]; int w;
-    struct Row { size_t off; };
-    struct Key {};
-    __device__ __forceinline__ Row row(int r) const { return Row{(size_t)r * w}; }
-    __device__ __forceinline__ Key key(int) const { return Key{}; }
-    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
-    __device__ __forceinline__ float4 at(const Row& r, int c) const {
-        const int sg = (c >= w) + (c >= 2 * w) + (c >= 3 * w);
-        const float* q = sg == 0 ? p[0] : sg == 1 ? p[1] : sg == 2 ? p[2] : p[3];
-        return ldg4(q + r.off + (c - sg * w));
-    }
-};
 struct EpSplitCols {                // column block s of the result goes to out[s] [rows][w]
     float* out[4]; int w;
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {

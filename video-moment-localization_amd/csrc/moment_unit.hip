@@ -53,23 +53,55 @@ void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ 
     }
 }
 
+// x1[n][:] = f_b[b][i][:] * f_b[b][j][:]   (the pair half of the moment unit's left operand, materialised once per layer
+// so that the forward contraction and the weight gradient read two plain matrices)
+__global__ void pair_product_kernel(const float* __restrict__ fb, const int* __restrict__ cells, size_t N, int L, int D4, float* __restrict__ x1)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * D4) return;
+    const size_t n = idx / D4; const int d4 = (int)(idx % D4);
+    const Cell cl = load_cell(cells, n);
+    const float* base = fb + (size_t)cl.b * L * D4 * 4;
+    stg4(x1 + idx * 4, f4mul(ldg4(base + ((size_t)cl.i * D4 + d4) * 4), ldg4(base + ((size_t)cl.j * D4 + d4) * 4)));
+}
+
+static CatMat pair_cat(const float* x1, const float* fcmean, int D)
+{
+    CatMat m;
+    m.p[0] = x1; m.p[1] = fcmean; m.p[2] = fcmean; m.p[3] = fcmean;
+    m.w = D;
+    return m;
+}
+
 }  // namespace smin
 
 using namespace smin;
 
 extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
-                                    int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu)
+                                    int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu, const float* x1)
 {
     (void)B;
+    hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
-    return launch_gemm_nt((hipStream_t)stream, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D},
-                          EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
+    if (!x1 || N == 0)
+        return launch_gemm_nt(st, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
+    return launch_gemm_nt(st, pair_cat(x1, fcmean, D), PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
+}
+
+extern "C" int smin_pair_product(void* stream, const float* fb, const int32_t* cells, int N, int L, int D, float* x1)
+{
+    SMIN_REQUIRE(D % 4 == 0);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (D / 4);
+    hipLaunchKernelGGL(pair_product_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb, cells, (size_t)N, L, D / 4, x1);
+    SMIN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                                     const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                                     float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
-                                    const float* dfcmean_acc)
+                                    const float* dfcmean_acc, const float* x1)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
@@ -88,7 +120,8 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
         if (all_valid) {
             rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
             if (rc) return rc;
-            rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+            if (x1) rc = launch_gemm_tn(st, PlainMat{dmu, D}, pair_cat(x1, fcmean, D), slab, bslab, N, D, 2 * D, sp);
+            else rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
         } else {
             rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
             if (rc) return rc;

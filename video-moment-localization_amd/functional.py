@@ -419,14 +419,16 @@ class MomentUnitFn(Function):
         N, D = fm.shape
         B, L, _ = fb.shape
         mu = torch.empty_like(fm)
-        _timed_call("moment_unit_fwd", "smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu))
-        ctx.save_for_backward(fcmean, fb, Wcat)
+        x1 = torch.empty_like(fm)                                     # f_b[i] * f_b[j], kept for the weight gradient
+        call("smin_pair_product", stream(), ptr(fb), ptr(layout.cells), N, L, D, ptr(x1))
+        _timed_call("moment_unit_fwd", "smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu), ptr(x1))
+        ctx.save_for_backward(fcmean, fb, Wcat, x1)
         ctx.layout = layout
         return mu, fcmean.view_as(fcmean)
 
     @staticmethod
     def backward(ctx, dmu, dacc):
-        fcmean, fb, Wcat = ctx.saved_tensors
+        fcmean, fb, Wcat, x1 = ctx.saved_tensors
         layout = ctx.layout
         N, D = fcmean.shape
         B, L, _ = fb.shape
@@ -438,7 +440,7 @@ class MomentUnitFn(Function):
         dWcat, dbcat = torch.empty_like(Wcat), fb.new_empty((D,))
         _, wp, wn = _unit_ws(layout, 4, D, 4, 1, fb.device)
         call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcmean), ptr(fb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
-             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid), ptr(dacc))
+             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid), ptr(dacc), ptr(x1))
         return dfcmean, dmu, dfb, dWcat, dbcat, None
 
 
