@@ -1,15 +1,16 @@
-// ContentAttention core on the matrix cores (reference models.py:207-226 and 253-266), fp32 MFMA 32x32x2.
+// ContentAttention core on the matrix cores (reference models.py:207-226 and 253-266), fp32 MFMA 16x16x4.
 //
-// One wave owns a tile of 8 cells = 32 "rows" (row j = 4*cell + clip; clips >= C are zero padding).  Rows live on
-// the MFMA column index (lane & 31), so every per-row vector (chat, a, q, gradients) is held by the lane pair
-// (j, j+32) as 2 x 64 registers in exactly the accumulator layout  d = 8*kg + 4*(lane>>5) + q :
-//   S^T[w][j]  = sum_d Mq[w][d] chat[j][d]          MFMA  A = Mq (LDS, rows = words), B = chat (registers)
-//   P          = softmax over words                  in-register: 16 values per lane + one cross-half exchange
-//   a^T[d][j]  = sum_w what[w][d] P^T[w][j]         MFMA  A = what^T (LDS), B = the P accumulator as is
+// One wave owns a tile of 4 cells = 16 "rows" (row n = 4*cell + clip; clips >= C are zero padding).  Rows live on
+// the MFMA column index (lane & 15); lane (n, kg = lane >> 4) holds the features d = 16*j + 4*kg + q of row n, so
+// every per-row vector (chat, a, q, gradients) is DL/4 registers in exactly the accumulator layout:
+//   S^T[w][n]  = sum_d Mq[w][d] chat[n][d]          MFMA  A = Mq (LDS, rows = words), B = chat (registers)
+//   P          = softmax over words                  in-register: 8 values per lane + two cross-lane exchanges
+//   a^T[d][n]  = sum_w what[w][d] P^T[w][n]         MFMA  A = what^T (LDS), B = the P accumulator as is
 //   q, Z = q q^T over the 4 clips of a cell, A = softmax(Z), cchat = A chat        VALU + DPP quad permutes
 // The backward pass mirrors it (dP^T = what . da^T and dchat^T += Mq^T . dS^T on MFMA) and streams da, dS and P
 // to HBM; the per-sample word-side reductions (dMq, dwhat, dshat, duq) are a second, MFMA "TN" kernel that reads
 // them back coalesced -- fixed-order partial slabs keep everything deterministic.
+// (A first version used 32-row tiles on the 32x32x2 MFMA: its backward needed 426 registers, one wave per SIMD.)
 #include "content_attn.h"
 
 namespace smin {
@@ -92,382 +93,12 @@ struct RowGeom {
     float m;            // cell mask
     bool nbok[4];       // neighbour clip c ^ o exists
 };
-// geometry without the mask (pure arithmetic); the caller supplies m once its load has landed
-__device__ __forceinline__ RowGeom row_geom_nomask(int n0, int n_end, int C, int lane) {
-    const int j = lane & 31, cell = n0 + (j >> 2), c = j & 3;
-    RowGeom g;
-    g.ok = cell < n_end && c < C;
-    const int cc = g.ok ? cell : n0;
-    g.row = cc * C + (g.ok ? c : 0);
-    g.m = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) g.nbok[o] = (c ^ o) < C;
-    return g;
-}
-__device__ __forceinline__ RowGeom row_geom(const int* cells, int n0, int n_end, int C, int lane) {
-    const int j = lane & 31, cell = n0 + (j >> 2), c = j & 3;
-    RowGeom g;
-    g.ok = cell < n_end && c < C;
-    const int cc = g.ok ? cell : n0;
-    g.row = cc * C + (g.ok ? c : 0);
-    g.m = g.ok ? (float)cells[4 * (size_t)cc + 3] : 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) g.nbok[o] = (c ^ o) < C;
-    return g;
-}
-
-// ---- forward pieces --------------------------------------------------------------------------------------------
-template <int DL>
-__device__ __forceinline__ void load_rows(float (&v)[DL / 8][4], const float* src, const RowGeom& g, int dl, int h) {
-#pragma unroll
-    for (int kg = 0; kg < DL / 8; ++kg) {
-        const int d = 8 * kg + 4 * h;
-        const float4 x = ldg4(src + (size_t)g.row * dl + min(d, dl - 4));
-        const bool ok = g.ok && d < dl;
-        v[kg][0] = ok ? x.x : 0.f; v[kg][1] = ok ? x.y : 0.f; v[kg][2] = ok ? x.z : 0.f; v[kg][3] = ok ? x.w : 0.f;
-    }
-}
-// the same in two halves: request the rows (raw, clamped addresses) early, mask them when they are first used
-template <int DL>
-__device__ __forceinline__ void request_rows(float4 (&raw)[DL / 8], const float* src, const RowGeom& g, int dl, int h) {
-#pragma unroll
-    for (int kg = 0; kg < DL / 8; ++kg) raw[kg] = ldg4(src + (size_t)g.row * dl + min(8 * kg + 4 * h, dl - 4));
-}
-template <int DL>
-__device__ __forceinline__ void accept_rows(float (&v)[DL / 8][4], const float4 (&raw)[DL / 8], const RowGeom& g, int dl, int h) {
-#pragma unroll
-    for (int kg = 0; kg < DL / 8; ++kg) {
-        const bool ok = g.ok && 8 * kg + 4 * h < dl;
-        v[kg][0] = ok ? raw[kg].x : 0.f; v[kg][1] = ok ? raw[kg].y : 0.f; v[kg][2] = ok ? raw[kg].z : 0.f; v[kg][3] = ok ? raw[kg].w : 0.f;
-    }
-}
-template <int DL>
-__device__ __forceinline__ void store_rows(float* dst, const float (&v)[DL / 8][4], const RowGeom& g, int dl, int h, float scale) {
-#pragma unroll
-    for (int kg = 0; kg < DL / 8; ++kg) {
-        const int d = 8 * kg + 4 * h;
-        if (g.ok && d < dl) stg4(dst + (size_t)g.row * dl + d, make_float4(v[kg][0] * scale, v[kg][1] * scale, v[kg][2] * scale, v[kg][3] * scale));
-    }
-}
-
-// P^T[w][j] (16 words per lane) from chat
-template <int DL>
-__device__ __forceinline__ void scores_softmax(float (&P)[16], const float (&ch)[DL / 8][4], const AttnLds<DL>& s, int Nq, float scale, int lane)
-{
-    constexpr int LDM = AttnLds<DL>::LDM;
-    const int l31 = lane & 31, h = lane >> 5;
-    f32x16 S;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-    for (int kg = 0; kg < DL / 8; ++kg) {
-        const float4 a4 = ldg4(s.sM + l31 * LDM + 8 * kg + 4 * h);
-        S = mfma32(a4.x, ch[kg][0], S); S = mfma32(a4.y, ch[kg][1], S);
-        S = mfma32(a4.z, ch[kg][2], S); S = mfma32(a4.w, ch[kg][3], S);
-        if ((kg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int w = wmap(r, h);
-        float v = (S[r] + s.sU[w]) * scale;
-        const float qm = s.sQ[w];
-        v = (qm == 0.f) ? -1e9f : v * qm;                         // models.py:216-218
-        v = (w < Nq) ? v : -INFINITY;
-        P[r] = v;
-        mx = fmaxf(mx, v);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float den = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { P[r] = expf(P[r] - mx); den += P[r]; }
-    den += __shfl_xor(den, 32);
-    const float inv = 1.0f / den;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) P[r] *= inv;
-}
-
-// one 32-feature tile of a^T[d][j] = sum_w what[w][d] P^T[w][j]   (accumulator layout: d = 32*dt + 8*(r>>2) + 4h + (r&3))
-template <int DL>
-__device__ __forceinline__ f32x16 attend_tile(int dt, const float (&P)[16], const AttnLds<DL>& s, int Nq, int lane)
-{
-    const int l31 = lane & 31, h = lane >> 5;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (8 * g < Nq) {
-            const float4 w4 = ldg4(s.sWT + (32 * dt + l31) * LDW + 8 * g + 4 * h);
-            acc = mfma32(w4.x, P[4 * g], acc); acc = mfma32(w4.y, P[4 * g + 1], acc);
-            acc = mfma32(w4.z, P[4 * g + 2], acc); acc = mfma32(w4.w, P[4 * g + 3], acc);
-        }
-    }
-    return acc;
-}
-
-// clip self-attention weights of this lane's row: Ao[o] = softmax_c'(q_c . q_c' / sqrt(dl))[c ^ o] * m,
-// q = chat * (a + shat); a is produced tile by tile on the matrix core and never held whole.
-template <int DL>
-__device__ __forceinline__ void clip_attention(float (&Ao)[4], const float (&ch)[DL / 8][4], const float (&P)[16],
-                                               const AttnLds<DL>& s, const RowGeom& g, int Nq, float scale, int lane)
-{
-    const int h = lane >> 5;
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
-        const f32x16 acc = attend_tile<DL>(dt, P, s, Nq, lane);
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            if (4 * dt + gq < DL / 8) {
-                const float4 sh = ldg4(s.sS + 8 * (4 * dt + gq) + 4 * h);
-                const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float qv = ch[(4 * dt + gq) % (DL / 8)][q] * (acc[4 * gq + q] + shv[q]);
-                    z[0] = fmaf(qv, qv, z[0]);
-                    fmac_nb3(z[1], z[2], z[3], qv, qv, qv, qv);
-                }
-            }
-            if (gq == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        z[o] = (z[o] + __shfl_xor(z[o], 32)) * scale;
-        z[o] = g.nbok[o] ? z[o] : -INFINITY;
-        mx = fmaxf(mx, z[o]);
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) { Ao[o] = expf(z[o] - mx); den += Ao[o]; }
-    const float inv = g.m / den;                                  // models.py:262-263: softmax, then * mask
-#pragma unroll
-    for (int o = 0; o < 4; ++o) Ao[o] *= inv;
-}
-
-template <int DL>
-__global__ __launch_bounds__(256, 2)
-void content_attn_fwd_mfma_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
-                                  const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
-                                  const float* __restrict__ shat, const float* __restrict__ qmask,
-                                  float* __restrict__ cchat, float* __restrict__ ccmean, int dl, int Nq, int cells_per_chunk, float scale)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
-    const int n_begin = s0 + chunk * cells_per_chunk;
-    if (n_begin >= s1) return;
-    const int n_end = min(s1, n_begin + cells_per_chunk);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
-    const float invC = 1.0f / C;
-    AttnLds<DL> s(smem_dyn, false);
-    stage_sample<DL>(s, false, Mq, uq, what, shat, qmask, b, dl, Nq);
-    __syncthreads();
-
-    for (int n0 = n_begin + 8 * wave; n0 < n_end; n0 += 32) {
-        const RowGeom g = row_geom(cells, n0, n_end, C, lane);
-        float ch[DL / 8][4], P[16], Ao[4];
-        load_rows<DL>(ch, chat, g, dl, h);
-        scores_softmax<DL>(P, ch, s, Nq, scale, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        clip_attention<DL>(Ao, ch, P, s, g, Nq, scale, lane);
-#pragma unroll
-        for (int kg = 0; kg < DL / 8; ++kg) {                       // cchat = A chat
-            float o4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x = ch[kg][q];
-                o4[q] = Ao[0] * x;
-                fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
-            }
-            const int d = 8 * kg + 4 * h;
-            if (cchat) {
-                if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
-            }
-            if (ccmean) {                                           // mean over the clips of the quad (padding lanes hold 0)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o4[q] = (o4[q] + nb<1>(o4[q]) + nb<2>(o4[q]) + nb<3>(o4[q])) * invC;
-                if (g.ok && (lane & 3) == 0 && d < dl)
-                    stg4(ccmean + (size_t)(g.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
-            }
-            if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ---- backward ---------------------------------------------------------------------------------------------------
-template <int DL>
-__global__ __launch_bounds__(256, 1)
-void content_attn_bwd_mfma_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
-                                  const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
-                                  const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
-                                  const float* __restrict__ shat, const float* __restrict__ qmask,
-                                  float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
-                                  int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell, float gscale)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    constexpr int LDM = AttnLds<DL>::LDM, KG = DL / 8;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
-    const int n_begin = s0 + chunk * cells_per_chunk;
-    if (n_begin >= s1) return;
-    const int n_end = min(s1, n_begin + cells_per_chunk);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-    AttnLds<DL> s(smem_dyn, true);
-    stage_sample<DL>(s, true, Mq, uq, what, shat, qmask, b, dl, Nq);
-    __syncthreads();
-
-    // one wave per SIMD: nothing but the wave's own instruction stream hides HBM latency, so the chat rows of the next
-    // tile are requested while this tile's tail runs, its mask at the top of this tile (a late scalar-ish load would
-    // have to drain every store in flight), and the gradient rows a phase before they are consumed
-    float4 chn[KG];
-    RowGeom gn = row_geom(cells, min(n_begin + 8 * wave, n_end - 1), n_end, C, lane);
-    if (n_begin + 8 * wave < n_end) request_rows<DL>(chn, chat, gn, dl, h);
-    for (int n0 = n_begin + 8 * wave; n0 < n_end; n0 += 32) {
-        const RowGeom g = gn;
-        // (unconditional: past the last tile the request is clamped onto the chunk's last cell and never accepted)
-        gn = row_geom_nomask(min(n0 + 32, n_end - 1), n_end, C, lane);
-        const int mn = cells[4 * (size_t)(gn.row / C) + 3];
-        float ch[KG][4], P[16], Ao[4];
-        accept_rows<DL>(ch, chn, g, dl, h);
-        float4 gq[KG];
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-            gq[kg] = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(8 * kg + 4 * h, dl - 4));
-        scores_softmax<DL>(P, ch, s, Nq, scale, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        clip_attention<DL>(Ao, ch, P, s, g, Nq, scale, lane);
-
-        // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
-        float dch[KG][4];
-        float dAo[4] = {0.f, 0.f, 0.f, 0.f};
-        const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const int d = 8 * kg + 4 * h;
-            const float4 g4 = gq[kg];
-            const bool ok = g.ok && d < dl;
-            const float gs = ok ? gscale : 0.f;
-            const float gv[4] = {g4.x * gs, g4.y * gs, g4.z * gs, g4.w * gs};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x = ch[kg][q], y = gv[q];
-                dAo[0] = fmaf(y, x, dAo[0]);
-                fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
-                dch[kg][q] = Ao[0] * y;
-                fmac_nb_sum(dch[kg][q], y, An1, An2, An3);
-            }
-            if ((kg & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // A = softmax(Z) * m ; Z symmetric in (c, c')
-        float sym[4];
-        {
-            float rd = 0.f, dZ[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { dAo[o] = (dAo[o] + __shfl_xor(dAo[o], 32)); rd = fmaf(Ao[o], dAo[o], rd); }
-            // Ao already carries m; with m == 0 everything below vanishes, with m == 1 this is the softmax Jacobian
-#pragma unroll
-            for (int o = 0; o < 4; ++o) dZ[o] = g.nbok[o] ? Ao[o] * (dAo[o] - rd) : 0.f;
-            sym[0] = 2.0f * dZ[0] * scale;
-            sym[1] = (dZ[1] + nb<1>(dZ[1])) * scale;
-            sym[2] = (dZ[2] + nb<2>(dZ[2])) * scale;
-            sym[3] = (dZ[3] + nb<3>(dZ[3])) * scale;
-        }
-        // per 32-feature tile: a (MFMA) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
-        //                      -> da to HBM and straight into  dP^T[w][j] += sum_d what[w][d] da^T[d][j]  (MFMA)
-        f32x16 dP;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dP[r] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
-            const f32x16 acc = attend_tile<DL>(dt, P, s, Nq, lane);
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (4 * dt + gq < KG) {
-                    constexpr int KGm = KG;
-                    const int kg = (4 * dt + gq) % KGm;
-                    const float4 sh = ldg4(s.sS + 8 * kg + 4 * h);
-                    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                    float da4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float tq = acc[4 * gq + q] + shv[q];
-                        const float qv = ch[kg][q] * tq;
-                        float dq = sym[0] * qv;
-                        fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
-                        dch[kg][q] = fmaf(dq, tq, dch[kg][q]);
-                        da4[q] = dq * ch[kg][q];
-                    }
-                    const int d = 8 * kg + 4 * h;
-                    if (g.ok && d < dl) stg4(da_out + (size_t)g.row * dl + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
-                    const float4 w4 = ldg4(s.sW + l31 * LDM + 8 * kg + 4 * h);
-                    dP = mfma32(w4.x, da4[0], dP); dP = mfma32(w4.y, da4[1], dP);
-                    dP = mfma32(w4.z, da4[2], dP); dP = mfma32(w4.w, da4[3], dP);
-                }
-                if (gq == 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        gn.m = gn.ok ? (float)mn : 0.f;
-        request_rows<DL>(chn, chat, gn, dl, h);
-        // P = softmax(S), S = (raw + u) * scale * qmask
-        float pd = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pd = fmaf(P[r], dP[r], pd);
-        pd += __shfl_xor(pd, 32);
-        float dS[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dS[r] = P[r] * (dP[r] - pd) * s.sQ[wmap(r, h)] * scale;
-        if (g.ok) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                stg4(ds_out + (size_t)g.row * 32 + 8 * gq + 4 * h, make_float4(dS[4 * gq], dS[4 * gq + 1], dS[4 * gq + 2], dS[4 * gq + 3]));
-                stg4(p_out + (size_t)g.row * 32 + 8 * gq + 4 * h, make_float4(P[4 * gq], P[4 * gq + 1], P[4 * gq + 2], P[4 * gq + 3]));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // raw = chat Mq^T :  dchat^T[d][j] += sum_w Mq[w][d] dS^T[w][j]   -> dchat = (...) * m   (chat = linear(fc) * m)
-#pragma unroll
-        for (int dt = 0; dt < (DL + 31) / 32; ++dt) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = (4 * dt + (r >> 2) < KG) ? dch[(4 * dt + (r >> 2)) % KG][r & 3] : 0.f;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (8 * gq < Nq) {
-                    const float4 m4 = ldg4(s.sMT + (32 * dt + l31) * LDW + 8 * gq + 4 * h);
-                    acc = mfma32(m4.x, dS[4 * gq], acc); acc = mfma32(m4.y, dS[4 * gq + 1], acc);
-                    acc = mfma32(m4.z, dS[4 * gq + 2], acc); acc = mfma32(m4.w, dS[4 * gq + 3], acc);
-                }
-            }
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (4 * dt + gq < KG) {
-                    const int d = 8 * (4 * dt + gq) + 4 * h;
-                    if (g.ok && d < dl)
-                        stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[4 * gq] * g.m, acc[4 * gq + 1] * g.m, acc[4 * gq + 2] * g.m, acc[4 * gq + 3] * g.m));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// =================================================================================================================
-// 16-row tiles on v_mfma_f32_16x16x4_f32.  Same mathematics and phase structure as the 32-row kernels above, with a
-// wave owning 4 cells = 16 rows: lane (n, kg) = (lane & 15, lane >> 4) holds the features d = 16*j + 4*kg + q of row n,
-// i.e. every per-row vector is DL/4 registers instead of DL/2.  That halves the register footprint (the 32-row
-// backward needs 426 registers and runs one wave per SIMD with nothing to hide HBM and LDS latency behind; this one
-// fits 256 and runs two), and a row's 16-byte loads of four neighbouring lanes form 64-byte segments.
+// ---- 16-row tiles on v_mfma_f32_16x16x4_f32 ---------------------------------------------------------------------
 // Accumulator layout of the 16x16x4 MFMA: register r of lane (n, kg) is element [4*kg + r][n], so
 //   S^T block b (words 16b .. 16b+15): lane holds words 16b + 4kg + r           -> P[4b + r]
 //   a^T block j (features 16j .. 16j+15): lane holds features 16j + 4kg + r      -> aligned with ch[j][r]
-// and, as above, the P / dS accumulators feed the next MFMA as B operands without any data movement.
+// and the P / dS accumulators feed the next MFMA as B operands without any data movement.  The backward fits 204
+// registers -> two waves per SIMD; a row's 16-byte loads of four neighbouring lanes form 64-byte segments.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float kg_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
