@@ -494,3 +494,46 @@ def test_query_encoder_matches_packed_lstm(dev, B, Nq, H):
     qd.fused_lstm = False
     fs2, fw2 = qd(x.to(dev), mask.to(dev))
     assert (fw2 - fw).abs().max().item() < 2e-5 and (fs2 - fs).abs().max().item() < 2e-5
+
+
+def test_gate_gradient_lists_and_pair_product(dev):
+    """GateFn with several views of hbar / f_m (their gradients are summed by the backward kernel from pointer lists)
+    against torch autograd on the formula of models.py:191, 272-274; and the moment unit with the materialised pair
+    product against the on-the-fly operand (same C entry point, x1 given / NULL)."""
+    import models
+    from vml_amd._lib import call, ptr, stream
+    from vml_amd.functional import GateFn
+    g = torch.Generator().manual_seed(11)
+    B, L, D = 3, 10, 48
+    mm = torch.triu(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0).repeat(B, 1, 1)
+    mm[1, :, 7:] = False
+    lay = models.vml_amd.CellLayout.from_mask(mm.to(dev))
+    N = lay.N
+    fm = torch.randn(N, D, generator=g, dtype=torch.float64)
+    fs = torch.randn(B, D, generator=g, dtype=torch.float64)
+    ws = [torch.randn(N, D, generator=g, dtype=torch.float64) for _ in range(6)]
+    fm_r, fs_r = fm.clone().requires_grad_(True), fs.clone().requires_grad_(True)
+    b_idx = lay.cells[:, 0].long().cpu()
+    hbar = torch.sigmoid(fm_r * fs_r[b_idx]) * fm_r
+    (sum((hbar * w).sum() for w in ws[:4]) + sum((fm_r * w).sum() for w in ws[4:])).backward()
+    fm_d, fs_d = fm.float().to(dev).requires_grad_(True), fs.float().to(dev).requires_grad_(True)
+    outs = GateFn.apply(fm_d, fs_d, lay, 4, 2)
+    assert len(outs) == 6 and (outs[0].detach().cpu().double() - hbar.detach()).abs().max().item() < 1e-5
+    sum((o * w.float().to(dev)).sum() for o, w in zip(outs, ws)).backward()
+    assert (fm_d.grad.cpu().double() - fm_r.grad).abs().max().item() < 2e-5 * max(1.0, fm_r.grad.abs().max().item())
+    assert (fs_d.grad.cpu().double() - fs_r.grad).abs().max().item() < 2e-4 * max(1.0, fs_r.grad.abs().max().item())
+    # moment unit forward: x1 given vs formed on the fly
+    fb = torch.randn(B, L, D, generator=g).to(dev)
+    fcm = torch.randn(N, D, generator=g).to(dev)
+    fmf = fm.float().to(dev)
+    Wcat = (torch.randn(D, 2 * D, generator=g) * 0.1).to(dev)
+    bcat = torch.randn(D, generator=g).to(dev)
+    x1 = torch.empty(N, D, device=dev)
+    call("smin_pair_product", stream(), ptr(fb), ptr(lay.cells), N, L, D, ptr(x1))
+    ci, cj = lay.cells[:, 1].long(), lay.cells[:, 2].long()
+    assert torch.equal(x1, fb[lay.cells[:, 0].long(), ci] * fb[lay.cells[:, 0].long(), cj])
+    mu_a, mu_b = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev)
+    call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fmf), ptr(fb), ptr(lay.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu_a), ptr(x1))
+    call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fmf), ptr(fb), ptr(lay.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu_b), None)
+    ref = torch.cat([x1, fcm], 1).double() @ Wcat.double().t() + bcat.double() + fmf.double()
+    assert (mu_a.double() - ref).abs().max().item() < 1e-4 and (mu_b.double() - ref).abs().max().item() < 1e-4
