@@ -36,6 +36,7 @@ def fwd(R, O, K, add, cells=False):
 
 
 def bwd(R, O, K):
+    import ctypes
     x = torch.randn(R, K, device=dev)
     WT = torch.randn(K, O, device=dev)
     dy = torch.randn(R, O, device=dev)
@@ -44,7 +45,8 @@ def bwd(R, O, K):
     db = torch.empty(O, device=dev)
     nb = _lib.load().smin_linear_rows_bwd_workspace_bytes(R, O, K)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    us = timeit(lambda: call("smin_linear_rows_bwd", stream(), ptr(dy), ptr(x), ptr(WT), R, O, K, ptr(dx), ptr(dW), ptr(db), ptr(ws), nb))
+    xs, dxs = (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_void_p * 1)(dx.data_ptr())
+    us = timeit(lambda: call("smin_linear_rows_bwd", stream(), ptr(dy), xs, 1, ptr(WT), R, O, K, dxs, ptr(dW), ptr(db), ptr(ws), nb))
     print(f"bwd R={R} O={O} K={K}: {us:7.1f} us (dx + dW)  {4*R*O*K/us/1e6:6.1f} TF")
 
 
