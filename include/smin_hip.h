@@ -236,9 +236,9 @@ int smin_bilstm_layer_fwd(void* stream, const float* X, const float* Wih_cat, co
                           const int32_t* len, int B, int Nq, int In, int H, float* G, float* Hout, float* Cs);
 size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H);
 /* dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H] (= d b_ih = d b_hh),
- * dWhh [2][4H][H].  Wih_catT [In][8H]; Wr4 [2][H][H][4] with Wr4[d][jj][u][r] = W_hh_d[4*jj+r][u]. */
+ * dWhh [2][4H][H].  Wih_catT [In][8H]; Whh [2][4H][H] (W_hh per direction, as nn.LSTM stores it). */
 int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
-                          const float* Wih_catT, const float* Wr4, const int32_t* len, int B, int Nq, int In, int H,
+                          const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
 
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */

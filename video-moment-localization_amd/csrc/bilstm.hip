@@ -122,24 +122,31 @@ void bilstm_fwd_kernel(float* __restrict__ G, const float* __restrict__ W4, cons
     }
 }
 
-// dG [B][Nq][2][4H] = gradient of the pre-activation gates (zero at padded positions)
-// Wr4 [2][H][H][4]   Wr4[d][jj][u][r] = W_hh_d[4*jj + r][u]
+// dG [B][Nq][2][4H] = gradient of the pre-activation gates (zero at padded positions);  Whh [2][4H][H] as nn.LSTM stores it.
+// Gate phase: thread (b, u) = (tid / Hp, tid % Hp) as in the forward.  Contraction phase dh[b][u] = sum_j dg[b][j] W[j][u]:
+// thread (jc, uq) takes a sixteenth of the 4H rows j for the four units 4uq .. 4uq+3 -- one float4 of W (coalesced over
+// uq) and one float4 of dg (the four samples, an LDS broadcast) feed 16 FMAs, so the LDS pipe issues a quarter of the
+// reads a one-unit-per-thread split needs (it was the bound of this kernel).
 __global__ __launch_bounds__(1024)
 void bilstm_bwd_kernel(const float* __restrict__ dHout, const float* __restrict__ G, const float* __restrict__ Cs,
-                       const float* __restrict__ Wr4, const int* __restrict__ len, int B, int Nq, int H, float* __restrict__ dG)
+                       const float* __restrict__ Whh, const int* __restrict__ len, int B, int Nq, int H, float* __restrict__ dG)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BS = LSTM_BS;
     const int Hp = blockDim.x >> 2;
     float* dgs = lds;                                              // [4H][BS]
-    float* part = lds + (size_t)4 * H * BS;                        // [4 jq][BS][Hp]
+    float* part = lds + (size_t)4 * H * BS;                        // [16 jc][BS][Hp]
     const int d = blockIdx.y, b0 = blockIdx.x * BS, u = threadIdx.x % Hp, jq = threadIdx.x / Hp;
     const bool own = u < H;
-    const int uu = own ? u : 0, H4 = 4 * H, jn = H / 4, j0 = jq * jn;   // this thread contracts rows 4*j0 .. 4*(j0+jn) of W_hh
+    const int H4 = 4 * H;
     const int bme = b0 + jq;
     const int L = bme < B ? min(len[bme], Nq) : 0;
+    const int nq = Hp >> 2, uq = threadIdx.x % nq, jc = threadIdx.x / nq;       // contraction roles: 16 row chunks x Hp/4 unit quads
+    const int rows = H4 / 16, jr0 = jc * rows;
+    const bool uok = 4 * uq < H;
+    const float4* wq = reinterpret_cast<const float4*>(Whh + (size_t)d * H4 * H) + (uok ? uq : 0);
+    const int ldw = H / 4;
     float dhn = 0.f, dcn = 0.f;
-    const float4* w = reinterpret_cast<const float4*>(Wr4) + ((size_t)d * H + j0) * H + uu;
     for (int s = Nq - 1; s >= 0; --s) {
         const bool act = s < L;
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -171,23 +178,34 @@ void bilstm_bwd_kernel(const float* __restrict__ dHout, const float* __restrict_
             for (int q = 0; q < 4; ++q) dgs[(size_t)(q * H + u) * BS + jq] = dg[q];
         }
         __syncthreads();
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll 8
-        for (int j = 0; j < jn; ++j) {
-            const float4 w4 = w[(size_t)j * H];
-            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+        f32x2 a[BS][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 g4 = *reinterpret_cast<const float4*>(dgs + (size_t)(4 * (j0 + j) + r) * BS);
-                const f32x2 ww = {wv[r], wv[r]};
-                a01 = __builtin_elementwise_fma(f32x2{g4.x, g4.y}, ww, a01);
-                a23 = __builtin_elementwise_fma(f32x2{g4.z, g4.w}, ww, a23);
+        for (int b = 0; b < BS; ++b) { a[b][0] = f32x2{0.f, 0.f}; a[b][1] = f32x2{0.f, 0.f}; }
+#pragma unroll 8
+        for (int j = 0; j < rows; ++j) {
+            const float4 w4 = wq[(size_t)(jr0 + j) * ldw];
+            const float4 g4 = *reinterpret_cast<const float4*>(dgs + (size_t)(jr0 + j) * BS);
+            const f32x2 w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int b = 0; b < BS; ++b) {
+                const f32x2 gb = {gv[b], gv[b]};
+                a[b][0] = __builtin_elementwise_fma(gb, w01, a[b][0]);
+                a[b][1] = __builtin_elementwise_fma(gb, w23, a[b][1]);
             }
         }
-        part[(jq * BS + 0) * Hp + u] = a01.x; part[(jq * BS + 1) * Hp + u] = a01.y;
-        part[(jq * BS + 2) * Hp + u] = a23.x; part[(jq * BS + 3) * Hp + u] = a23.y;
+        if (uok) {
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+                *reinterpret_cast<float4*>(part + (size_t)(jc * BS + b) * Hp + 4 * uq) = make_float4(a[b][0].x, a[b][0].y, a[b][1].x, a[b][1].y);
+        }
         __syncthreads();
-        if (act) dhn = (part[(0 * BS + jq) * Hp + u] + part[(1 * BS + jq) * Hp + u]) + (part[(2 * BS + jq) * Hp + u] + part[(3 * BS + jq) * Hp + u]);
+        if (act && own) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += part[(size_t)(k * BS + jq) * Hp + u];
+            dhn = sum;
+        }
         // no third barrier: dgs is rewritten only after every thread has passed the barrier above (its reads are over),
         // and part only after the next step's first barrier, which every thread reaches after the reads of this line
     }
@@ -221,6 +239,8 @@ extern "C" int smin_bilstm_layer_fwd(void* stream, const float* X, const float* 
     if (rc) return rc;
     const int Hp = cdiv(H, 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)H * LSTM_BS + (size_t)16 * LSTM_BS * Hp);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, G, W4, len, B, Nq, H, Hout, Cs);
     SMIN_LAUNCH_CHECK();
     return 0;
@@ -235,7 +255,7 @@ extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, i
 
 // dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H]
 extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
-                                     const float* Wih_catT, const float* Wr4, const int32_t* len, int B, int Nq, int In, int H,
+                                     const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                                      float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -247,8 +267,11 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
     float* Hprev = dG + (size_t)R * H8;
     float* slab = Hprev + (size_t)2 * R * H;
     const int Hp = cdiv(H, 64) * 64;
-    const size_t lds = sizeof(float) * ((size_t)H4 * LSTM_BS + (size_t)4 * LSTM_BS * Hp);
-    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Wr4, len, B, Nq, H, dG);
+    const size_t lds = sizeof(float) * ((size_t)H4 * LSTM_BS + (size_t)16 * LSTM_BS * Hp);
+    SMIN_REQUIRE(H4 % 16 == 0);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
     SMIN_LAUNCH_CHECK();
     int rc;
     if (dX) {

@@ -273,8 +273,7 @@ class BiLstmLayerFn(Function):
         dX = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dWih, dbias, dWhh = torch.empty_like(Wih), x.new_empty((8 * H,)), torch.empty_like(Whh)
         _, wp, wn = _ws(_lib.load().smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, H), x.device)
-        Wr4 = Whh.view(2, H, 4, H).permute(0, 1, 3, 2).contiguous()         # [2, row // 4, u, row % 4]
-        call("smin_bilstm_layer_bwd", stream(), ptr(dH), ptr(x), ptr(Hout), ptr(G), ptr(Cs), ptr(Wih.t().contiguous()), ptr(Wr4), ptr(length),
+        call("smin_bilstm_layer_bwd", stream(), ptr(dH), ptr(x), ptr(Hout), ptr(G), ptr(Cs), ptr(Wih.t().contiguous()), ptr(Whh), ptr(length),
              B, Nq, In, H, ptr(dX), ptr(dWih), ptr(dbias), ptr(dWhh), wp, wn)
         H4 = 4 * H
         return (dX, None, dWih[:H4], dWhh[0], dbias[:H4], dbias[:H4], dWih[H4:], dWhh[1], dbias[H4:], dbias[H4:])
