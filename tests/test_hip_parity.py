@@ -537,3 +537,31 @@ def test_gate_gradient_lists_and_pair_product(dev):
     call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fmf), ptr(fb), ptr(lay.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu_b), None)
     ref = torch.cat([x1, fcm], 1).double() @ Wcat.double().t() + bcat.double() + fmf.double()
     assert (mu_a.double() - ref).abs().max().item() < 1e-4 and (mu_b.double() - ref).abs().max().item() < 1e-4
+
+
+def test_degenerate_samples_and_empty_batch(dev):
+    """A sample with a single valid snippet, a sample with none, inference under no_grad, and a batch without any valid
+    cell (N = 0) with its backward -- the edge cases of the packed layout."""
+    import models
+    from oracle import smin_oracle as O
+    T, L, C, D, dl, layers, Din, Nq, Hh = 32, 8, 4, 64, 32, 3, 24, 6, 32
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+    batch = O.synthetic_batch(3, T, L, Nq, Din, seed=5)
+    batch["length_mask"][1] = False
+    batch["length_mask"][1, 0] = True
+    batch["length_mask"][2] = False
+    batch["moment_mask"] = torch.triu(batch["length_mask"].unsqueeze(2) & batch["length_mask"].unsqueeze(1))
+    batch["video_mask"][2] = 0
+    batch["video_features"][2] = 0
+    ref = O.smin_forward({k: v.clone() for k, v in sd.items()}, dict(T=T, L=L, C=C), *H.model_inputs(batch))
+    with torch.no_grad():
+        out = m(*H.model_inputs(batch, dev))
+    for a, b in zip(out, ref):
+        assert (a.cpu() - b).abs().max().item() < SCORE_TOL
+    batch["length_mask"][:] = False
+    batch["moment_mask"][:] = False
+    out = m(*H.model_inputs(batch, dev))
+    assert all(float(o.detach().abs().max()) == 0.0 for o in out)
+    (out[0].sum() + out[1].sum()).backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())

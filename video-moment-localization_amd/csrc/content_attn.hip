@@ -565,8 +565,9 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
                                      const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                                      float* cc, float* ccmean)
 {
-    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32 && (cc || ccmean));
+    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
+    SMIN_REQUIRE(cc || ccmean);
     return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
 }
 
@@ -583,9 +584,10 @@ extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float
                                      float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
-    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32 && (dcc || dccmean));
-    SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));
+    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
+    SMIN_REQUIRE(dcc || dccmean);
+    SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));
     const int M = N * C;
     float* w = reinterpret_cast<float*>(ws);
     float* aws = w + (((size_t)M * dl + 3) & ~(size_t)3);
