@@ -17,6 +17,7 @@ size_t content_attn_bwd_ws_floats(int M, int B, int dl);
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale);
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
+                            const float* dmean2 /* nullable [N][dl]: a second, per-cell gradient added as dmean2 * mscale */, float mscale);
 
 }  // namespace smin

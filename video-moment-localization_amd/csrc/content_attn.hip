@@ -273,7 +273,8 @@ void content_attn_bwd16_kernel(const float* __restrict__ chat, const float* __re
                                const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                                const float* __restrict__ shat, const float* __restrict__ qmask,
                                float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
-                               int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell, float gscale)
+                               int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell, float gscale,
+                               const float* __restrict__ dmean2, float mscale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int LDM = AttnLds<DL>::LDM, KJ = DL / 16;
@@ -295,6 +296,11 @@ void content_attn_bwd16_kernel(const float* __restrict__ chat, const float* __re
 #pragma unroll
         for (int j = 0; j < KJ; ++j)
             gq[j] = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(16 * j + 4 * kg, dl - 4));
+        float4 gm[KJ];                                              // second consumer's gradient (per cell), when there is one
+        if (dmean2) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) gm[j] = ldg4(dmean2 + (size_t)(g.row / C) * dl + min(16 * j + 4 * kg, dl - 4));
+        }
         scores_softmax16<DL>(P, ch, s, Nq, scale, lane);
         __builtin_amdgcn_sched_barrier(0);
         clip_attention16<DL>(Ao, ch, P, s, g, Nq, scale, lane);
@@ -306,8 +312,13 @@ void content_attn_bwd16_kernel(const float* __restrict__ chat, const float* __re
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
             const int d = 16 * j + 4 * kg;
-            const float gs = (g.ok && d < dl) ? gscale : 0.f;
-            const float gv[4] = {gq[j].x * gs, gq[j].y * gs, gq[j].z * gs, gq[j].w * gs};
+            const bool dok = g.ok && d < dl;
+            const float gs = dok ? gscale : 0.f;
+            float gv[4] = {gq[j].x * gs, gq[j].y * gs, gq[j].z * gs, gq[j].w * gs};
+            if (dmean2) {
+                const float ms = dok ? mscale : 0.f;
+                gv[0] = fmaf(gm[j].x, ms, gv[0]); gv[1] = fmaf(gm[j].y, ms, gv[1]); gv[2] = fmaf(gm[j].z, ms, gv[2]); gv[3] = fmaf(gm[j].w, ms, gv[3]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float x = ch[j][q], y = gv[q];
@@ -515,7 +526,8 @@ size_t content_attn_bwd_ws_floats(int M, int B, int dl)
 template <int DL>
 static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale)
+                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
+                 const float* dmean2, float mscale)
 {
     int cpc, mc; chunking(L, &cpc, &mc);
     float* da = ws;
@@ -523,7 +535,7 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
     float* P = dS + (size_t)M * 32;
     float* slab = P + (size_t)M * 32;
     hipLaunchKernelGGL((content_attn_bwd16_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(true), st, chat, dcchat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell, gscale);
+                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL((content_attn_wordgrad_kernel<DL>), dim3(ATTN_SPLITS, B), dim3(256), 0, st, chat, da, dS, P, row_ptr, L, C, dl, ATTN_SPLITS, slab);
     SMIN_LAUNCH_CHECK();
@@ -535,22 +547,13 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale)
+                            float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
+                            const float* dmean2, float mscale)
 {
-    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
-    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
-    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
-    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale);
-}
-
-// g[n][c][:] = dcc[n][c][:] + dccmean[n][:] / C        (both consumers of a middle layer's attention output)
-__global__ void attn_grad_combine_kernel(const float* __restrict__ dcc, const float* __restrict__ dccmean, float* __restrict__ out,
-                                         size_t total4, int C, int dl4, float invC)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total4) return;
-    const size_t row = idx / dl4; const int d4 = (int)(idx % dl4);
-    stg4(out + idx * 4, f4fma(ldg4(dccmean + ((row / C) * dl4 + d4) * 4), invC, ldg4(dcc + idx * 4)));
+    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
+    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
+    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
+    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
 }
 
 }  // namespace smin
@@ -573,7 +576,7 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
 
 extern "C" size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl)
 {
-    return sizeof(float) * (content_attn_bwd_ws_floats(N * C, B, dl) + (size_t)N * C * dl + 64);
+    return sizeof(float) * (content_attn_bwd_ws_floats(N * C, B, dl) + 64);
 }
 
 // Gradients dcc [N*C][dl] and/or dccmean [N][dl] (either may be NULL, not both) -> dchat and the per-sample word-side
@@ -589,16 +592,10 @@ extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float
     SMIN_REQUIRE(dcc || dccmean);
     SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));
     const int M = N * C;
-    float* w = reinterpret_cast<float*>(ws);
-    float* aws = w + (((size_t)M * dl + 3) & ~(size_t)3);
-    const float* g = dcc; int per_cell = 0; float gscale = 1.0f;
-    if (dcc && dccmean) {
-        const size_t tot4 = (size_t)M * (dl / 4);
-        hipLaunchKernelGGL(attn_grad_combine_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, st, dcc, dccmean, w, tot4, C, dl / 4, 1.0f / C);
-        SMIN_LAUNCH_CHECK();
-        g = w;
-    } else if (!dcc) {
-        g = dccmean; per_cell = 1; gscale = 1.0f / C;
-    }
-    return launch_content_attn_bwd(st, chat, g, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, per_cell, gscale);
+    float* aws = reinterpret_cast<float*>(ws);
+    const float* g = dcc; const float* g2 = nullptr; int per_cell = 0; float gscale = 1.0f;
+    if (dcc && dccmean) g2 = dccmean;                               // both consumers: summed while the rows are loaded
+    else if (!dcc) { g = dccmean; per_cell = 1; gscale = 1.0f / C; }
+    return launch_content_attn_bwd(st, chat, g, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq,
+                                   per_cell, gscale, g2, 1.0f / C);
 }

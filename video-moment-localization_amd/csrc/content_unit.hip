@@ -211,7 +211,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     rc = launch_reduce_slabs(st, slab1, dWc, D * dl, sp1); if (rc) return rc;
     rc = launch_reduce_slabs(st, bslab1, dbc, D, sp1); if (rc) return rc;
     // (c) attention core backward -> dchat (already multiplied by m: masked cells write 0)
-    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f);
+    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f, nullptr, 0.f);
     if (rc) return rc;
     // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl;  dhbar = sum_c dout (gate term)
     if (C == 4) {
