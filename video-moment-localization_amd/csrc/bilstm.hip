@@ -281,8 +281,7 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
     const int sp1 = tn_splits(R, H8, In);
     float* bslab = slab + (size_t)sp1 * H8 * In;
     rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab, dWih_cat, H8 * In, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs(st, bslab, dbias_cat, H8, sp1); if (rc) return rc;
+    rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1); if (rc) return rc;
     const size_t tot = (size_t)2 * R * H;
     hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev);
     SMIN_LAUNCH_CHECK();

@@ -378,11 +378,9 @@ extern "C" int smin_boundary_unit_bwd(void* stream, const float* dout, const flo
     // projections: dfb += dQb Wq ; dWq = dQb^T fb ; dbq = colsum dQb ; dfw += dKb Wk ; dWk = dKb^T fw ; dbk = colsum dKb
     int rc = launch_gemm_nt(st, PlainMat{dQb, D}, PlainMat{WqT, D}, EpAccum{dfb}, B * L, D, D); if (rc) return rc;
     rc = launch_gemm_tn(st, PlainMat{dQb, D}, PlainMat{fb, D}, slab1, bslab1, B * L, D, D, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab1, dWq, D * D, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs(st, bslab1, dbq, D, sp1); if (rc) return rc;
+    rc = launch_reduce_slabs2(st, slab1, dWq, D * D, bslab1, dbq, D, sp1); if (rc) return rc;
     rc = launch_gemm_nt(st, PlainMat{dKb, D}, PlainMat{WkT, D}, EpAccum{dfw}, B * Nq, D, D); if (rc) return rc;
     rc = launch_gemm_tn(st, PlainMat{dKb, D}, PlainMat{fw, D}, slab2, bslab2, B * Nq, D, D, sp2); if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab2, dWk, D * D, sp2); if (rc) return rc;
-    rc = launch_reduce_slabs(st, bslab2, dbk, D, sp2); if (rc) return rc;
+    rc = launch_reduce_slabs2(st, slab2, dWk, D * D, bslab2, dbk, D, sp2); if (rc) return rc;
     return 0;
 }

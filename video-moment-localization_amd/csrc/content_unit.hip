@@ -208,8 +208,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
         rc = launch_gemm_tn(st, dout, PlainMat{cchat, dl}, slab1, bslab1, M, D, dl, sp1);
         if (rc) return rc;
     }
-    rc = launch_reduce_slabs(st, slab1, dWc, D * dl, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs(st, bslab1, dbc, D, sp1); if (rc) return rc;
+    rc = launch_reduce_slabs2(st, slab1, dWc, D * dl, bslab1, dbc, D, sp1); if (rc) return rc;
     // (c) attention core backward -> dchat (already multiplied by m: masked cells write 0)
     rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f, nullptr, 0.f);
     if (rc) return rc;
@@ -227,8 +226,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     // (e) dWch[dl, D] = dchat^T @ fc ; dbch = colsum(dchat)
     rc = launch_gemm_tn(st, PlainMat{dchat, dl}, PlainMat{fc, D}, slab2, bslab2, M, dl, D, sp2);
     if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab2, dWch, dl * D, sp2); if (rc) return rc;
-    rc = launch_reduce_slabs(st, bslab2, dbch, dl, sp2); if (rc) return rc;
+    rc = launch_reduce_slabs2(st, slab2, dWch, dl * D, bslab2, dbch, dl, sp2); if (rc) return rc;
     return 0;
 }
 

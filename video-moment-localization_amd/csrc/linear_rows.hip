@@ -109,8 +109,7 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
     if (nseg == 1) rc = launch_gemm_tn(st, PlainMat{dy, O}, PlainMat{xs[0], K}, slab, bslab, R, O, Kt, sp);
     else rc = launch_gemm_tn(st, PlainMat{dy, O}, cat_of(xs, nseg, K), slab, bslab, R, O, Kt, sp);
     if (rc) return rc;
-    rc = launch_reduce_slabs(st, slab, dW, O * Kt, sp); if (rc) return rc;
-    if (dbias) { rc = launch_reduce_slabs(st, bslab, dbias, O, sp); if (rc) return rc; }
+    rc = launch_reduce_slabs2(st, slab, dW, O * Kt, bslab, dbias, O, sp); if (rc) return rc;
     return 0;
 }
 

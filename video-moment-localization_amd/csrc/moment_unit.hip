@@ -128,8 +128,7 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
             rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
         }
         if (rc) return rc;
-        rc = launch_reduce_slabs(st, slab, dWcat, D * 2 * D, sp); if (rc) return rc;
-        rc = launch_reduce_slabs(st, bslab, dbcat, D, sp); if (rc) return rc;
+        rc = launch_reduce_slabs2(st, slab, dWcat, D * 2 * D, bslab, dbcat, D, sp); if (rc) return rc;
     } else {
         (void)hipMemsetAsync(dWcat, 0, sizeof(float) * (size_t)D * 2 * D, st);
         (void)hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);

@@ -155,15 +155,13 @@ extern "C" int smin_score_map_bwd(void* stream, const float* dpm, const float* d
     if (N > 0) {
         hipLaunchKernelGGL(score_map_bwd_kernel, dim3(nch), dim3(128), 0, st, dpm, pm, fm, cells, N, L, D, wm, dfm, part, bpart);
         SMIN_LAUNCH_CHECK();
-        int rc = launch_reduce_slabs(st, part, dwm, D, nch); if (rc) return rc;
-        rc = launch_reduce_slabs(st, bpart, dbm, 1, nch); if (rc) return rc;
+        int rc = launch_reduce_slabs2(st, part, dwm, D, bpart, dbm, 1, nch); if (rc) return rc;
     } else {
         (void)hipMemsetAsync(dwm, 0, sizeof(float) * D, st);
         (void)hipMemsetAsync(dbm, 0, sizeof(float), st);
     }
     hipLaunchKernelGGL(score_heads_bwd_kernel, dim3(hch), dim3(128), 0, st, dpsea, psea, fb, BL, D, wb, lmask, dfb, hpart, hbpart);
     SMIN_LAUNCH_CHECK();
-    int rc = launch_reduce_slabs(st, hpart, dwb, 3 * D, hch); if (rc) return rc;
-    rc = launch_reduce_slabs(st, hbpart, dbb, 3, hch); if (rc) return rc;
+    int rc = launch_reduce_slabs2(st, hpart, dwb, 3 * D, hbpart, dbb, 3, hch); if (rc) return rc;
     return 0;
 }
