@@ -565,3 +565,23 @@ def test_degenerate_samples_and_empty_batch(dev):
     assert all(float(o.detach().abs().max()) == 0.0 for o in out)
     (out[0].sum() + out[1].sum()).backward()
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_bench_contract_line(dev):
+    """bench.py prints one JSON line with the keys the driver reads (short run of a small workload)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--workload", "charadessta"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["higher_is_better"] is True
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert "workload" in j["config"] and j["value"] > 0
