@@ -439,6 +439,8 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
     const int full_rounds = total / GEMM_SLOTS;
     if (full_rounds >= 1 && total % GEMM_SLOTS != 0 && (total % GEMM_SLOTS) < (3 * GEMM_SLOTS) / 4)
         main_tiles_m = (full_rounds * GEMM_SLOTS) / tiles_n;         // whole rounds of 128-row tiles, rest as mini tiles
+    else if (total * 3 <= GEMM_SLOTS)
+        main_tiles_m = 0;                                            // fewer tiles than CUs: 32-row tiles spread the rows four times wider
     const int rem_rows = M - main_tiles_m * 128;
     const int mini_blocks = rem_rows > 0 ? cdiv(rem_rows, 32) * tiles_n : 0;
     const int main_blocks = cdiv(main_tiles_m, 8) * 8 * tiles_n;
