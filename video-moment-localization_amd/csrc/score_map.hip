@@ -49,14 +49,15 @@ void score_heads_fwd_kernel(const float* __restrict__ fb, int BL, int D, const f
     }
 }
 
-// chunk of 256 cells per workgroup: dfm = dz * wm ; partial[chunk][d] = sum dz * fm ; partial bias
+// chunk of 64 cells per workgroup (a thread walks its chunk serially, one dependent load chain per cell: short chunks
+// and many workgroups keep it HBM-bound): dfm = dz * wm ; partial[chunk][d] = sum dz * fm ; partial bias
 __global__ __launch_bounds__(128)
 void score_map_bwd_kernel(const float* __restrict__ dpm, const float* __restrict__ pm, const float* __restrict__ fm,
                           const int* __restrict__ cells, int N, int L, int D, const float* __restrict__ wm,
                           float* __restrict__ dfm, float* __restrict__ partial, float* __restrict__ bpartial)
 {
     const int chunk = blockIdx.x;
-    const int n0 = chunk * 256, n1 = min(N, n0 + 256);
+    const int n0 = chunk * 64, n1 = min(N, n0 + 64);
     float bsum = 0.f;
     for (int d = threadIdx.x * 4; d < D || d == threadIdx.x * 4; d += 512) {
         const bool dok = d < D;
@@ -145,7 +146,7 @@ extern "C" int smin_score_map_bwd(void* stream, const float* dpm, const float* d
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
     const int BL = B * L;
-    const int nch = cdiv(N > 0 ? N : 1, 256), hch = cdiv(BL, 64);
+    const int nch = cdiv(N > 0 ? N : 1, 64), hch = cdiv(BL, 64);
     float* w = reinterpret_cast<float*>(ws);
     float* part = w;                                   // [nch][D]
     float* bpart = part + (size_t)nch * D;             // [nch]  (padded to 4)

@@ -107,7 +107,7 @@ extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int N
     // moment unit bwd: dX1 [N][D] + TN slabs + bias slabs
     size_t moment = (size_t)N * D + (size_t)(N > 0 ? tn_splits(N, D, 2 * D) : 1) * ((size_t)D * 2 * D + D);
     // boundary / score: per-row partials
-    size_t other = (size_t)N + 8 * (size_t)B * 64 * D + (size_t)N * 4;
+    size_t other = (size_t)N + 8 * (size_t)B * 64 * D + (size_t)N * 4 + (size_t)(N / 32 + 1) * (D + 4);
     // boundary unit bwd (L <= 64 assumed here; the host adds 2*B*L*L + 3*B*L*D for longer maps)
     other += (size_t)B * 64 * 64 * 2 + (size_t)B * 64 * D * 3 + (size_t)B * 64 * 64 + (size_t)B * 64 * D + 2 * (size_t)64 * ((size_t)D * D + D);
     size_t fl = content > moment ? content : moment;
