@@ -39,7 +39,12 @@ class VideoEncoder(nn.Module):
     def forward(self, video_features, video_mask):
         vm = video_mask.float()
         pos = torch.arange(video_mask.shape[1], device=video_features.device)
-        return self.ve(video_features) * vm + self.pe(pos).unsqueeze(0) * vm
+        if video_features.is_cuda and self.d0 % 4 == 0 and self.d % 4 == 0 and video_features.dtype == torch.float32:
+            B, T, _ = video_features.shape                          # the projection on the library's MFMA engine
+            y = LinearRowsFn.apply(self.ve.weight, self.ve.bias, None, None, 1, video_features.reshape(B * T, self.d0)).view(B, T, self.d)
+        else:
+            y = self.ve(video_features)
+        return y * vm + self.pe(pos).unsqueeze(0) * vm
 
 
 _SIDE_STREAMS = {}
