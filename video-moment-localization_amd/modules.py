@@ -48,6 +48,10 @@ class VideoEncoder(nn.Module):
 
 
 _SIDE_STREAMS = {}
+# parameters are deliberately used on two streams (see SMIN._forward_stream); autograd then synchronises the streams where a
+# gradient is accumulated, which is what we want -- not worth a warning per backward pass
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
 
 def _side_stream(device):
@@ -284,17 +288,14 @@ class MomentUnit(nn.Module):
         self.conv_layer_fb = nn.Conv2d(D, D, 1)
         self.conv_layer_fc = nn.Conv2d(D, D, 1)
 
-    def forward_stream(self, fcmean, fm, f_b, layout):
-        """(mu, view of fcmean for the next consumer of the clip-mean chain)"""
+    def cat_weights(self):
+        """(Wcat [D, 2D], bcat [D]): the two 1x1 convolutions as one contraction over [f_b[i]*f_b[j] | mean_c f_c]."""
         D = self.D
         Wcat = torch.cat([self.conv_layer_fb.weight.view(D, D), self.conv_layer_fc.weight.view(D, D)], dim=1)
-        bcat = self.conv_layer_fb.bias + self.conv_layer_fc.bias
-        return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)
+        return Wcat, self.conv_layer_fb.bias + self.conv_layer_fc.bias
 
     def forward_packed(self, fcmean, fm, f_b, layout):
-        D = self.D
-        Wcat = torch.cat([self.conv_layer_fb.weight.view(D, D), self.conv_layer_fc.weight.view(D, D)], dim=1)
-        bcat = self.conv_layer_fb.bias + self.conv_layer_fc.bias
+        Wcat, bcat = self.cat_weights()
         return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)[0]
 
     def forward(self, f_c, f_m, f_b, moment_mask):
@@ -384,17 +385,37 @@ class SMIN(nn.Module):
         gradients back to the reference's parameters."""
         T, L, C, dl = self.T, self.L, self.C, self.dl
         N = layout.N
+        nl = len(self.smis)
+        cus = [smi.content_unit for smi in self.smis]
+        cur = torch.cuda.current_stream(f.device)
+        side = _side_stream(f.device) if self.overlap_boundary else cur
+        # Everything that depends only on parameters and on the query encoding -- the word-side operands of every layer,
+        # the dl x dl weight products, constants and concatenations: ~100 tiny launches forward, more backward -- is
+        # formed up front on the second stream.  Their backward nodes then run there too, off the main stream's chain
+        # (nothing on the critical path waits for a parameter gradient).
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            consts, bsum = [], None
+            for cu in cus:
+                consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
+                bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
+            Wch_all, const_all = torch.cat([cu.linear_c_hat.weight for cu in cus]), torch.cat(consts)
+            words = [cu.word_operands(fw, fs, query_mask) for cu in cus]
+            Pcats = [[torch.cat([torch.matmul(cus[k].linear_c_hat.weight, cus[l].linear_c.weight) for l in range(lo, min(lo + 4, k))], dim=1)
+                      for lo in range(0, k, 4)] for k in range(nl)]
+            mu_w = [smi.moment_unit.cat_weights() for smi in self.smis]
+        cur.wait_stream(side)
+        if side is not cur:
+            # allocator bookkeeping for tensors that cross streams: made on one stream, read on the other
+            for t in [Wch_all, const_all] + [x for w in words for x in w] + [x for ps in Pcats for x in ps] + [x for w in mu_w for x in w]:
+                t.record_stream(cur)
+            for t in (fw, fs, query_mask, length_mask, layout.cells, layout.row_ptr, layout.cellmap):
+                t.record_stream(side)
         fm, fb = ProposalMeansFn.apply(f, layout, T, L, C)
         # every layer's clip-mean term and constant in one pass over f
-        cus = [smi.content_unit for smi in self.smis]
-        consts, bsum = [], None
-        for cu in cus:
-            consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
-            bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
-        g_all = LinearRowsFn.apply(torch.cat([cu.linear_c_hat.weight for cu in cus]), None, None, None, 1, f.reshape(-1, self.D))
-        pgs = ClipWindowMeansFn.apply(g_all.view(f.shape[0], T, -1), torch.cat(consts), layout, T, L, C, len(cus))
+        g_all = LinearRowsFn.apply(Wch_all, None, None, None, 1, f.reshape(-1, self.D))
+        pgs = ClipWindowMeansFn.apply(g_all.view(f.shape[0], T, -1), const_all, layout, T, L, C, nl)
         cumean, H, hist = None, None, []
-        nl = len(self.smis)
         for k, smi in enumerate(self.smis):
             last = k == nl - 1
             cu = smi.content_unit
@@ -408,19 +429,19 @@ class SMIN(nn.Module):
             # The boundary unit reads only the layer inputs: a chain of small, latency-bound launches that runs on a
             # second HIP stream beside the content stream (whose attention kernels leave most of a CU's registers and
             # LDS free) and joins before the moment unit; autograd replays its backward on the same stream.
-            cur = torch.cuda.current_stream(fm.device)
-            side = _side_stream(fm.device) if self.overlap_boundary else cur
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 bu = smi.boundary_unit.forward_packed(fb, fw, fs, hbar_b, query_mask, length_mask, layout)
+            if side is not cur:
+                fb.record_stream(side)
+                hbar_b.record_stream(side)
             Wch = cu.linear_c_hat.weight
             chat = pgs[k]
-            for lo in range(0, len(hist), 4):                              # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
+            for n_part, lo in enumerate(range(0, len(hist), 4)):           # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
                 part = hist[lo:lo + 4]
                 hp = LinearRowsFn.apply(Wch, None, None, None, 1, H) if lo == 0 else None   # (sum_l hbar_l) Wch^T, per cell
-                chat = LinearRowsFn.apply(torch.cat([torch.matmul(Wch, Wc_l) for _, Wc_l, _ in part], dim=1), None, chat, hp, C,
-                                          *[cc_l for cc_l, _, _ in part])
-            Mq, uq, what, shat, qm = cu.word_operands(fw, fs, query_mask)
+                chat = LinearRowsFn.apply(Pcats[k][n_part], None, chat, hp, C, *[cc_l for cc_l, _, _ in part])
+            Mq, uq, what, shat, qm = words[k]
             cc, ccmean = ContentAttnFn.apply(chat, Mq, uq, what, shat, qm, layout, C, not last)
             cumean = LinearRowsFn.apply(cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1, ccmean)
             if not last:
@@ -432,8 +453,9 @@ class SMIN(nn.Module):
                     Hsum = H
                 hist.append((cc, cu.linear_c.weight, cu.linear_c.bias))
             cur.wait_stream(side)
-            bu.record_stream(cur)
-            fm, cumean = smi.moment_unit.forward_stream(cumean, fm_res, bu, layout)
+            if side is not cur:
+                bu.record_stream(cur)
+            fm, cumean = MomentUnitFn.apply(cumean, fm_res, bu, mu_w[k][0], mu_w[k][1], layout)
             fb = bu
         return self.localization.forward_packed(fm, fb, length_mask, layout)
 
