@@ -194,7 +194,8 @@ int smin_compute_ious(void* stream, const float* pm, const float* ps, const floa
 
 /* out[s][n*C + c][:] = m * (mean over clip c of cell n of g[b][t][s*W:(s+1)*W] + bias[s*W:(s+1)*W])
  * g [B][T][nseg*W] (nseg <= 8: one segment per layer), out [nseg][N*C][W]; ws >= 8*B*(T+1)*nseg*W bytes. */
-int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias, const int32_t* cells, int N, int B, int T, int L, int C,
+int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias /* [bias_len], first features only */, int bias_len,
+                               const int32_t* cells, int N, int B, int T, int L, int C,
                                int W, int nseg, float* out, void* ws, size_t ws_bytes);
 /* dout: HOST array of nseg device pointers, dout[s] [N*C][W] -> dg [B][T][nseg*W]; ws >= 4*B*T*nseg*W bytes. */
 int smin_clip_window_means_bwd(void* stream, const float* const* dout, const int32_t* cells, const int32_t* row_ptr,

@@ -41,7 +41,7 @@ SIGNATURES = {
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
-    "smin_clip_window_means_fwd": [_vp] * 4 + [_i] * 7 + [_vp, _vp, _sz],
+    "smin_clip_window_means_fwd": [_vp] * 3 + [_i, _vp] + [_i] * 7 + [_vp, _vp, _sz],
     "smin_clip_window_means_bwd": [_vp] * 5 + [_i] * 7 + [_vp, _vp, _sz, _vp, _vp],
     "smin_content_attn_fwd": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
     "smin_content_attn_bwd_workspace_bytes": [_i] * 4,

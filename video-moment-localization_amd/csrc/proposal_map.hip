@@ -468,10 +468,11 @@ extern "C" int smin_proposal_map_bwd(void* stream, const float* dfc, const float
 // Clip means of per-frame features g [B][T][nseg*W] over every cell's clip windows, plus a bias on every clip row
 // (empty clips included), one output tensor per segment of W features:
 //   out[s][n*C + c][:] = m * (mean_{t in clip c of cell n} g[b][t][s*W : (s+1)*W] + bias[s*W : (s+1)*W])
+// (bias covers the first bias_len features only: later segments get their constant where its gradient is free)
 // With g = f [Wch_1; ..; Wch_k]^T this is every layer's linear_c_hat applied to ProposalGeneration's f_c without ever
 // forming f_c (content stream).  Backward: smin_clip_window_means_bwd.
 __global__ __launch_bounds__(128)
-void clip_window_means_kernel(const double* __restrict__ Pf, const float* __restrict__ bias, const int* __restrict__ cells,
+void clip_window_means_kernel(const double* __restrict__ Pf, const float* __restrict__ bias, int bias_len, const int* __restrict__ cells,
                               int T, int L, int C, int W, int nseg, size_t rows, float* __restrict__ out)
 {
     // one workgroup per cell; a thread owns float4 columns of the nseg*W features and walks the cell's clips along the
@@ -483,7 +484,7 @@ void clip_window_means_kernel(const double* __restrict__ Pf, const float* __rest
     const double inv = (double)(1.0f / (float)cs);
     for (int d = threadIdx.x * 4; d < D; d += 512) {
         const int sg = d / W, dw = d - sg * W;
-        const float4 b4 = (bias && cl.m != 0) ? ldg4(bias + d) : f4zero();
+        const float4 b4 = (d < bias_len && cl.m != 0) ? ldg4(bias + d) : f4zero();
         const double* pb = Pf + ((size_t)cl.b * (T + 1) + cl.i * r) * D + d;
         double4_ lo = {pb[0], pb[1], pb[2], pb[3]};
         float* o = out + ((size_t)sg * rows + (size_t)n * C) * W + dw;
@@ -502,19 +503,20 @@ void clip_window_means_kernel(const double* __restrict__ Pf, const float* __rest
 }
 
 
-extern "C" int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias, const int32_t* cells, int N, int B, int T, int L, int C,
+extern "C" int smin_clip_window_means_fwd(void* stream, const float* g, const float* bias, int bias_len, const int32_t* cells, int N, int B, int T, int L, int C,
                                           int W, int nseg, float* out, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
     const int D = W * nseg;
     SMIN_REQUIRE(W % 4 == 0 && nseg >= 1 && nseg <= 8 && L >= 1 && T >= L && T % L == 0 && C >= 1 && D <= 2048);
+    SMIN_REQUIRE(bias_len % 4 == 0 && bias_len >= 0 && bias_len <= D);
     SMIN_REQUIRE(ws_bytes >= sizeof(double) * (size_t)B * (T + 1) * D);
     if (N == 0) return 0;
     double* Pf = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL((time_scan_kernel<true>), dim3(cdiv(D, 64), B), dim3(1024), 0, st, g, (const float*)nullptr, T, L, D, Pf, (float*)nullptr);
     SMIN_LAUNCH_CHECK();
     const size_t rows = (size_t)N * C;
-    hipLaunchKernelGGL(clip_window_means_kernel, dim3(N), dim3(128), 0, st, Pf, bias, cells, T, L, C, W, nseg, rows, out);
+    hipLaunchKernelGGL(clip_window_means_kernel, dim3(N), dim3(128), 0, st, Pf, bias, bias ? bias_len : 0, cells, T, L, C, W, nseg, rows, out);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

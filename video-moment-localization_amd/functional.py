@@ -122,6 +122,7 @@ class ProposalMeansFn(Function):
 
 class ClipWindowMeansFn(Function):
     """out[s][n, c] = mean over clip c of cell n of g[b, t, s*W:(s+1)*W] + bias[s*W:(s+1)*W], one tensor per segment s
+    (bias may cover only the first k segments: k*W entries)
     -- every layer's linear_c_hat applied to ProposalGeneration's f_c (reference models.py:117, 247) through
     g = f [Wch_1; ..]^T, without forming f_c.  Mask-driven layouts only."""
 
@@ -132,8 +133,9 @@ class ClipWindowMeansFn(Function):
         W = D // nseg
         out = g.new_empty((nseg, layout.N * C, W))
         _, wp, wn = _ws(8 * B * (T + 1) * D, g.device)
-        call("smin_clip_window_means_fwd", stream(), ptr(g), ptr(bias), ptr(layout.cells), layout.N, B, T, L, C, W, nseg, ptr(out), wp, wn)
-        ctx.layout, ctx.dims = layout, (B, T, L, C, W, nseg)
+        nb = 0 if bias is None else bias.numel()                     # bias may cover only the first segments
+        call("smin_clip_window_means_fwd", stream(), ptr(g), ptr(bias), nb, ptr(layout.cells), layout.N, B, T, L, C, W, nseg, ptr(out), wp, wn)
+        ctx.layout, ctx.dims, ctx.nb = layout, (B, T, L, C, W, nseg), nb
         return tuple(out[s] for s in range(nseg))
 
     @staticmethod
@@ -149,7 +151,7 @@ class ClipWindowMeansFn(Function):
         eo, et = clip_event_table(ref.device, T, L, C)
         call("smin_clip_window_means_bwd", stream(), arr, ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
              layout.N, B, T, L, C, W, nseg, ptr(dg), wp, wn, ptr(eo), ptr(et))
-        dbias = torch.cat([d.sum(dim=0) for d in douts]) if ctx.needs_input_grad[1] else None
+        dbias = torch.cat([d.sum(dim=0) for d in douts[:ctx.nb // W]]) if (ctx.needs_input_grad[1] and ctx.nb) else None
         return dg, dbias, None, None, None, None, None
 
 

@@ -399,7 +399,10 @@ class SMIN(nn.Module):
             for cu in cus:
                 consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
                 bsum = cu.linear_c.bias if bsum is None else bsum + cu.linear_c.bias
-            Wch_all, const_all = torch.cat([cu.linear_c_hat.weight for cu in cus]), torch.cat(consts)
+            Wch_all = torch.cat([cu.linear_c_hat.weight for cu in cus])
+            # layer 0's constant rides on the clip means; later layers get theirs in the contraction that forms chat_k,
+            # whose weight-gradient pass yields the constant's gradient (a column sum) for free
+            const_all = consts[0]
             words = [cu.word_operands(fw, fs, query_mask) for cu in cus]
             Pcats = [[torch.cat([torch.matmul(cus[k].linear_c_hat.weight, cus[l].linear_c.weight) for l in range(lo, min(lo + 4, k))], dim=1)
                       for lo in range(0, k, 4)] for k in range(nl)]
@@ -407,7 +410,7 @@ class SMIN(nn.Module):
         cur.wait_stream(side)
         if side is not cur:
             # allocator bookkeeping for tensors that cross streams: made on one stream, read on the other
-            for t in [Wch_all, const_all] + [x for w in words for x in w] + [x for ps in Pcats for x in ps] + [x for w in mu_w for x in w]:
+            for t in [Wch_all] + consts + [x for w in words for x in w] + [x for ps in Pcats for x in ps] + [x for w in mu_w for x in w]:
                 t.record_stream(cur)
             for t in (fw, fs, query_mask, length_mask, layout.cells, layout.row_ptr, layout.cellmap):
                 t.record_stream(side)
@@ -440,7 +443,7 @@ class SMIN(nn.Module):
             for n_part, lo in enumerate(range(0, len(hist), 4)):           # [cc_1 | cc_2 | ..] [Wch Wc_1 | Wch Wc_2 | ..]^T
                 part = hist[lo:lo + 4]
                 hp = LinearRowsFn.apply(Wch, None, None, None, 1, H) if lo == 0 else None   # (sum_l hbar_l) Wch^T, per cell
-                chat = LinearRowsFn.apply(Pcats[k][n_part], None, chat, hp, C, *[cc_l for cc_l, _, _ in part])
+                chat = LinearRowsFn.apply(Pcats[k][n_part], consts[k] if lo == 0 else None, chat, hp, C, *[cc_l for cc_l, _, _ in part])
             Mq, uq, what, shat, qm = words[k]
             cc, ccmean = ContentAttnFn.apply(chat, Mq, uq, what, shat, qm, layout, C, not last)
             cumean = LinearRowsFn.apply(cu.linear_c.weight, cu.linear_c.bias, cumean, hbar_c, 1, ccmean)
