@@ -242,6 +242,12 @@ int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, cons
                           const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
 
+/* ---- packed valid-cell layout from a (B, L, L) mask (uint8 / bool, non-zero = valid).  all_cells = 0: list the valid
+ * cells (m = 1); 1: list every (b, i, j) with m = mask.  cells [N][4] = {b, i, j, m} sorted by (b, i, j); row_ptr
+ * [B*L + 1]; cellmap [B][L][L] = cell id or -1.  The caller sizes cells from the count of listed cells. */
+int smin_build_cells(void* stream, const uint8_t* mask, int B, int L, int all_cells,
+                     int32_t* cells, int32_t* row_ptr, int32_t* cellmap);
+
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);

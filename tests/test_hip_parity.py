@@ -585,3 +585,26 @@ def test_bench_contract_line(dev):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["higher_is_better"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert "workload" in j["config"] and j["value"] > 0
+
+
+def test_layout_build_kernels(dev):
+    """smin_build_cells (two launches) against the torch formulation of the packed layout: mask-driven and all-cells
+    lists, ragged / empty rows, L not a multiple of 64, more than 1024 rows."""
+    import models
+    CellLayout = models.vml_amd.CellLayout
+    g = torch.Generator().manual_seed(9)
+    for (B, L) in [(3, 6), (5, 70), (40, 33), (2, 130)]:
+        mm = torch.rand(B, L, L, generator=g) > 0.6
+        mm[0, 1] = False                                              # an empty row
+        if B > 2:
+            mm[2] = False                                             # an empty sample
+        ref = CellLayout.from_mask(mm)                                # CPU tensors: torch formulation
+        got = CellLayout.begin(mm.to(dev)).finish()                   # HIP kernels (count copied asynchronously)
+        assert got.N == ref.N and got.all_valid
+        for name in ("cells", "row_ptr", "cellmap"):
+            assert torch.equal(getattr(got, name).cpu(), getattr(ref, name)), (B, L, name)
+        assert torch.equal(got.bidx.cpu(), ref.bidx) and torch.equal(got.jidx.cpu(), ref.jidx)
+        ref_all, got_all = CellLayout.all_cells(mm), CellLayout.all_cells(mm.to(dev))
+        assert got_all.N == B * L * L and not got_all.all_valid
+        for name in ("cells", "row_ptr", "cellmap"):
+            assert torch.equal(getattr(got_all, name).cpu(), getattr(ref_all, name)), (B, L, name, "all")

@@ -8,17 +8,38 @@ import torch
 
 
 class CellLayout:
-    __slots__ = ("cells", "row_ptr", "cellmap", "N", "B", "L", "bidx", "iidx", "jidx", "all_valid")
+    __slots__ = ("cells", "row_ptr", "cellmap", "N", "B", "L", "_idx", "all_valid")
 
     def __init__(self, cells, row_ptr, cellmap, B, L, idx, all_valid=False):
         self.cells, self.row_ptr, self.cellmap = cells, row_ptr, cellmap
         self.all_valid = all_valid                                # mask-driven list: every listed cell has m == 1
         self.N, self.B, self.L = int(cells.shape[0]), B, L
-        self.bidx, self.iidx, self.jidx = idx[:, 0], idx[:, 1], idx[:, 2]
+        self._idx = idx                                           # (N, 3) int64, or None: derived from cells on first use
+
+    def _index(self):
+        if self._idx is None:
+            self._idx = self.cells[:, :3].long()
+        return self._idx
+
+    bidx = property(lambda self: self._index()[:, 0])
+    iidx = property(lambda self: self._index()[:, 1])
+    jidx = property(lambda self: self._index()[:, 2])
 
     @staticmethod
     def _build(present, flag, N=None):
         B, L, _ = present.shape
+        if present.is_cuda and (N is not None or present is not flag):
+            # HIP path: two launches (csrc/layout.hip).  all_cells lists every (b, i, j): N = B*L*L without asking the device
+            from . import _lib
+            all_cells = present is not flag
+            N = B * L * L if all_cells else N
+            mask = flag.contiguous()
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else (mask != 0).view(torch.uint8)
+            cells = torch.empty((N, 4), dtype=torch.int32, device=flag.device)
+            row_ptr = torch.empty(B * L + 1, dtype=torch.int32, device=flag.device)
+            cellmap = torch.empty((B, L, L), dtype=torch.int32, device=flag.device)
+            _lib.call("smin_build_cells", _lib.stream(), _lib.ptr(mask), B, L, int(all_cells), _lib.ptr(cells), _lib.ptr(row_ptr), _lib.ptr(cellmap))
+            return CellLayout(cells, row_ptr, cellmap, B, L, None, not all_cells)
         if N is None:
             idx = present.nonzero()                               # (N, 3) sorted by (b, i, j); one host sync
         else:
