@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import bench, models
 from vml_amd import loss_fn
 dev = torch.device("cuda:0")
-T, L, C, D, dl, layers, Din, Nq, Hh, B = bench.WORKLOADS["activitynet_t256"]
+T, L, C, D, dl, layers, Din, Nq, Hh, B = bench.WORKLOADS[os.environ.get("WL", "activitynet_t256")]
 torch.manual_seed(43)
 model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4)
