@@ -228,6 +228,16 @@ int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, 
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
 int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 
+/* ---- VideoEncoder (models.py:25-36) fused with the backbone's Hadamard product (models.py:81-83):
+ *   fv[b][t][:] = (x[b][t][:] W^T + bias + pe[t][:]) * vmask[b][t]     f[b][t][:] = fv[b][t][:] * fs[b][:]
+ * x [B*T][Din], W [D][Din], pe [>=T][D] (rows 0..T-1 are used), vmask [B*T] fp32, fs [B][D]; outputs fv, f [B*T][D]. */
+int smin_video_encoder_fwd(void* stream, const float* x, const float* W, const float* bias, const float* pe, const float* vmask,
+                           const float* fs, int B, int T, int Din, int D, float* fv, float* f);
+size_t smin_video_encoder_bwd_workspace_bytes(int B, int T, int Din, int D);
+/* df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D] */
+int smin_video_encoder_bwd(void* stream, const float* df, const float* fv, const float* fs, const float* vmask, const float* x,
+                           int B, int T, int Din, int D, float* dW, float* dbias, float* dpe, float* dfs, void* ws, size_t ws_bytes);
+
 /* ---- QueryEncoder's bidirectional LSTM layer (models.py:38-64: nn.LSTM over a packed, padded batch), one layer per
  * call, both directions.  X [B*Nq][In]; Wih_cat [8H][In] = [W_ih; W_ih_reverse]; bias_cat [8H] = b_ih + b_hh per
  * direction; W4 [2][H][H][4] with W4[d][k][u][g] = W_hh_d[g*H+u][k]; len [B] valid lengths (device).  Outputs: Hout

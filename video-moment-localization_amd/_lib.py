@@ -51,13 +51,16 @@ SIGNATURES = {
     "smin_linear_rows_bwd_workspace_bytes": [_i] * 3,
     "smin_linear_rows_bwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
     "smin_group_sum": [_vp, _vp, _i, _i, _i, _vp],
+    "smin_video_encoder_fwd": [_vp] * 7 + [_i] * 4 + [_vp] * 2,
+    "smin_video_encoder_bwd_workspace_bytes": [_i] * 4,
+    "smin_video_encoder_bwd": [_vp] * 6 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
     "smin_bilstm_layer_fwd": [_vp] * 6 + [_i] * 4 + [_vp] * 3,
     "smin_bilstm_layer_bwd_workspace_bytes": [_i] * 4,
     "smin_bilstm_layer_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
             "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz,
-            "smin_bilstm_layer_bwd_workspace_bytes": _sz}
+            "smin_bilstm_layer_bwd_workspace_bytes": _sz, "smin_video_encoder_bwd_workspace_bytes": _sz}
 
 _lib = None
 _ws = {}

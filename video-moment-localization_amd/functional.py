@@ -245,6 +245,35 @@ class LinearRowsFn(Function):
         return (dW, dbias, (dy if need[2] else None), dcells, None) + (tuple(dxs) if want_dx else (None,) * nseg)
 
 
+class VideoFuseFn(Function):
+    """f = ((x W^T + b + pe[t]) * vmask) * f_s  -- VideoEncoder.forward and the backbone's Hadamard product (reference
+    models.py:25-36, 81-83) as one contraction with a fused epilogue.  x [B, T, Din] (no gradient), pe [T_emb, D]."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, pe, vmask, fs):
+        x, W, bias, pe, vmask, fs = map(_c, (x, W, bias, pe, vmask, fs))
+        B, T, Din = x.shape
+        D = W.shape[0]
+        fv, f = x.new_empty((B, T, D)), x.new_empty((B, T, D))
+        call("smin_video_encoder_fwd", stream(), ptr(x), ptr(W), ptr(bias), ptr(pe), ptr(vmask), ptr(fs), B, T, Din, D, ptr(fv), ptr(f))
+        ctx.save_for_backward(x, fv, fs, vmask)
+        ctx.dims, ctx.pe_rows = (B, T, Din, D), pe.shape[0]
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        x, fv, fs, vmask = ctx.saved_tensors
+        B, T, Din, D = ctx.dims
+        df = _c(df)
+        dW, dbias = x.new_empty((D, Din)), x.new_empty((D,))
+        dpe = x.new_zeros((ctx.pe_rows, D)) if ctx.pe_rows != T else x.new_empty((T, D))
+        dfs = torch.empty_like(fs)
+        _, wp, wn = _ws(_lib.load().smin_video_encoder_bwd_workspace_bytes(B, T, Din, D), x.device)
+        call("smin_video_encoder_bwd", stream(), ptr(df), ptr(fv), ptr(fs), ptr(vmask), ptr(x), B, T, Din, D,
+             ptr(dW), ptr(dbias), ptr(dpe), ptr(dfs), wp, wn)
+        return None, dW, dbias, dpe, None, dfs
+
+
 class BiLstmLayerFn(Function):
     """One bidirectional LSTM layer over a padded batch with per-sample lengths (reference models.py:46-58: nn.LSTM on
     pack_padded_sequence / pad_packed_sequence).  x [B, Nq, In], length int32 [B] (device) -> [B, Nq, 2H], zero at

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .cells import CellLayout
-from .functional import (BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
+from .functional import (VideoFuseFn, BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
                          ProposalMapFn, ProposalMeansFn, ScoreMapFn)
 
 
@@ -144,8 +144,15 @@ class Backbone(nn.Module):
         self.queryencoder = QueryEncoder(max_query_length, lstm_hidden_size)
 
     def forward(self, video_features, video_mask, query_features, query_mask):
-        fv = self.videoencoder(video_features, video_mask)
         fs, fw = self.queryencoder(query_features, query_mask)
+        ve = self.videoencoder
+        if (video_features.is_cuda and video_features.dtype == torch.float32 and ve.d0 % 4 == 0 and ve.d % 4 == 0
+                and video_features.shape[1] <= ve.pe.weight.shape[0]):
+            # projection + position embedding + mask + Hadamard product with f_s in one contraction (video_encoder.hip)
+            B, T, _ = video_features.shape
+            f = VideoFuseFn.apply(video_features, ve.ve.weight, ve.ve.bias, ve.pe.weight, video_mask.reshape(B * T).float(), fs)
+            return f, fs, fw
+        fv = ve(video_features, video_mask)
         return fv * fs.unsqueeze(1), fs, fw
 
 
