@@ -137,6 +137,8 @@ def main():
     model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
     if os.environ.get("SMIN_NO_OVERLAP"):
         model.overlap_boundary = False
+    if os.environ.get("SMIN_NO_PREP_OVERLAP"):
+        model.overlap_prep = False
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
     net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)

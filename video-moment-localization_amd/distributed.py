@@ -48,6 +48,11 @@ def wrap(model, device=None, bucket_cap_mb=8):
         # gloo stages every bucket through the host and synchronises the streams a gradient touched: with the two-stream
         # step that serialises the whole backward pass (8x slower, measured); RCCL is unaffected
         model.overlap_boundary = False
+    if getattr(model, "overlap_prep", False):
+        # DDP creates every parameter's gradient accumulator on the stream it is constructed on; parameters that the step
+        # touches only on the second stream then make the main stream wait at each accumulation (measured +0.7 ms over
+        # keeping that work on the main stream; the boundary unit's overlap still pays)
+        model.overlap_prep = False
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)

@@ -378,6 +378,7 @@ class SMIN(nn.Module):
 
     content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
     overlap_boundary = True        # boundary unit on a second HIP stream beside the content stream
+    overlap_prep = True            # parameter-only work (word-side operands, weight products) on that stream as well
 
     def _forward_stream(self, f, fs, fw, query_mask, length_mask, layout):
         """The same network with the content unit's two linear maps re-associated (exact in real arithmetic).
@@ -400,8 +401,9 @@ class SMIN(nn.Module):
         # the dl x dl weight products, constants and concatenations: ~100 tiny launches forward, more backward -- is
         # formed up front on the second stream.  Their backward nodes then run there too, off the main stream's chain
         # (nothing on the critical path waits for a parameter gradient).
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        prep = side if self.overlap_prep else cur
+        prep.wait_stream(cur)
+        with torch.cuda.stream(prep):
             consts, bsum = [], None
             for cu in cus:
                 consts.append(cu.linear_c_hat.bias if bsum is None else cu.linear_c_hat.bias + torch.mv(cu.linear_c_hat.weight, bsum))
@@ -414,11 +416,12 @@ class SMIN(nn.Module):
             Pcats = [[torch.cat([torch.matmul(cus[k].linear_c_hat.weight, cus[l].linear_c.weight) for l in range(lo, min(lo + 4, k))], dim=1)
                       for lo in range(0, k, 4)] for k in range(nl)]
             mu_w = [smi.moment_unit.cat_weights() for smi in self.smis]
-        cur.wait_stream(side)
-        if side is not cur:
+        cur.wait_stream(prep)
+        if prep is not cur:
             # allocator bookkeeping for tensors that cross streams: made on one stream, read on the other
             for t in [Wch_all] + consts + [x for w in words for x in w] + [x for ps in Pcats for x in ps] + [x for w in mu_w for x in w]:
                 t.record_stream(cur)
+        if side is not cur:
             for t in (fw, fs, query_mask, length_mask, layout.cells, layout.row_ptr, layout.cellmap):
                 t.record_stream(side)
         fm, fb = ProposalMeansFn.apply(f, layout, T, L, C)
