@@ -8,9 +8,13 @@ ActivityNet-Captions-shaped input (BASELINE.json configs[2]: activitynet.yml wit
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement).  `value` = dense proposals (B_total * L * L)
-per second with all inputs resident in HBM; `roofline` is measured live with HIP events around the dominant
-kernel (the fp32-MFMA moment-unit GEMM) inside the timed steps; `cpu_baseline` times the CPU oracle
-(a port of the reference's dense algorithm) on a bounded micro-batch on the host cores (rank 0, N=1 only).
+per second of the full train step (Adam included) with all inputs resident in HBM; `ms_fwd_bwd` is the same step
+without the optimizer (SURVEY 8d's metric definition), timed right after.  `roofline` is measured live with HIP
+events recorded by the library on the launch stream (smin_prof_*) around the three moment-unit contractions
+(forward / input gradient / weight gradient) and the attention core inside the timed steps; `roofline.step` prices
+the whole step against both roofs with SURVEY 8d's per-cell figures.  `cpu_baseline` times the CPU oracle (a port of
+the reference's dense algorithm -- the reference itself cannot travel to the GPU box) on micro-batches of 8 on the
+host cores (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -63,10 +67,12 @@ def make_batch(B, T, L, Nq, Din, seed, device):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
+def cpu_baseline(cfg, seconds_budget=25.0):
     """Time the CPU oracle (oracle/smin_oracle.py, a port of the reference's dense algorithm, pinned to the
-    reference by tests/golden) on a micro-batch of the same workload.  Checker code, used here only as the
-    reported baseline."""
+    reference by tests/golden) on micro-batches of the same workload, BASELINE.md section 3 style: micro-batch 8 (1 for
+    the 512 x 512 map), the 16 host threads of a one-GPU box's CPU share, median step.  Checker code, used here only as the
+    reported baseline; `kind` stays "port" because /root/reference does not exist on the GPU box."""
+    import statistics
     from oracle import smin_oracle as O
     from tests import helpers as H
     T, L, C, D, dl, layers, Din, Nq, Hh, _ = cfg
@@ -74,9 +80,10 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(16, avail))                    # a 1-GPU box owns a 16-core share of the host
-    torch.set_num_threads(threads)
-    Bc = 2 if L >= 64 else 8
+    # a one-GPU box owns a 16-core share of a 256-CPU host: the affinity mask still lists every CPU, and a 256-thread
+    # torch pool on 16 cores ran this step 100x slower (318 s) than 16 threads do
+    torch.set_num_threads(max(1, min(16, avail)))
+    Bc = 8 if L <= 64 else 1
     sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.0)
     sd = {k: v.requires_grad_(True) for k, v in sd.items()}
     batch = O.synthetic_batch(Bc, T, L, Nq, Din, seed=0)
@@ -92,13 +99,31 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     step()                                              # warm-up (page-in, thread pool)
     first = time.perf_counter() - t0
     times = []
-    while sum(times) + first < seconds_budget and len(times) < 5:
+    while sum(times) + first < seconds_budget and len(times) < 9:
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
-    t = min(times) if times else first
+    t = statistics.median(times) if times else first
     return {"value": Bc * L * L / t, "unit": "proposals/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times) or 1} fwd+bwd steps of a B={Bc} micro-batch of the same workload, best step {t:.3f} s"}
+            "sample": f"{len(times) or 1} fwd+bwd steps of a B={Bc} micro-batch of the same workload after one warm-up, "
+                      f"median step {t:.3f} s (min {min(times or [first]):.3f}), {torch.get_num_threads()} threads of {os.cpu_count()} host CPUs"}
+
+
+def step_work(C, D, dl, Nq, layers):
+    """Per-valid-cell work of one fwd+bwd step (fp32), SURVEY 8d.  Algorithmic = the reference's formulation; executed =
+    what this build's content stream runs (the content unit's D x dl maps re-associated into the dl space)."""
+    f_layer = 4 * C * D * dl + 2 * C * dl * dl + 4 * C * Nq * dl + 4 * C * C * dl + 4 * D * D
+    flops_alg = 3 * (layers * f_layer + 2 * D)
+    f_exec = 2 * D
+    for k in range(layers):
+        f_exec += 4 * D * D                              # moment unit: [x1 | mean_c f_c] Wcat^T
+        f_exec += 2 * C * dl * dl * k                    # chat_k: history [cc_1 .. cc_k] (Wch Wc_l)^T
+        f_exec += (2 * dl * D) if k > 0 else 0           # chat_k: gate term (sum hbar) Wch^T
+        f_exec += 4 * C * Nq * dl + 4 * C * C * dl       # attention core with W_q / W_k folded per sample
+        f_exec += 2 * dl * D                             # clip-mean update (mean_c cc) Wc^T
+    U = C * D + D
+    bytes_alg = 4 * ((U + layers * (2 * U + D) + D) + (layers * 3 * U + U + 2 * D))
+    return flops_alg, 3 * f_exec, bytes_alg
 
 
 def main():
@@ -128,6 +153,7 @@ def main():
     models.vml_amd._lib.load()
     models.vml_amd.set_gemm_mode(args.gemm)
     dp.init(backend=os.environ.get("SMIN_DIST_BACKEND", "nccl"), device=dev)   # nccl == RCCL on ROCm (xGMI inside the node)
+    backend, world_seen = dp.describe()                      # what the collective library itself reports
 
     cfg = WORKLOADS[args.workload]
     T, L, C, D, dl, layers, Din, Nq, Hh, B = cfg
@@ -144,14 +170,14 @@ def main():
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)
     n_valid = int(batch["moment_mask"].sum().item())
 
-    def step():
+    def step(with_opt=True):
         opt.zero_grad(set_to_none=True)
         pm, ps, pe, pa = net(batch["video_features"], batch["video_mask"], batch["query_features"], batch["query_mask"],
                              batch["length_mask"], batch["moment_mask"])
         loss = loss_fn(pm, batch["ym"], batch["sm"], batch["moment_mask"], ps, batch["ys"], batch["ss"], pe, batch["ye"], batch["se"],
                        pa, batch["ya"], batch["length_mask"])
         loss.backward()
-        if not args.no_optimizer:
+        if with_opt and not args.no_optimizer:
             opt.step()
         return loss
 
@@ -159,51 +185,103 @@ def main():
         dp.barrier()
         torch.cuda.synchronize()
 
+    lib = models.vml_amd._lib
     for _ in range(args.warmup):
         step()
-    Fn.KERNEL_EVENTS.clear()
-    Fn.RECORD_EVENTS = True                                  # HIP events around the dominant kernel, on its stream
+    lib.prof_enable(True)                                    # HIP events around the tagged launches, on their launch stream
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    Fn.RECORD_EVENTS = False
+    lib.prof_enable(False)
+    prof = lib.prof_read()
     elapsed = dp.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
+    # the same K steps without the optimizer: SURVEY 8d defines the metric on zero_grad + fwd + loss + bwd (+ all-reduce)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(with_opt=False)
+    fence()
+    elapsed_fb = dp.max_over_ranks(time.perf_counter() - t0, dev)
     n_valid_total = int(dp.sum_over_ranks(n_valid, dev))
 
-    # dominant kernel: moment-unit forward GEMM  mu = X[N, 2D] @ Wcat[D, 2D]^T  (one launch per layer per step)
-    durs = [s.elapsed_time(e) for (name, s, e) in Fn.KERNEL_EVENTS if name == "moment_unit_fwd"]
-    roofline = None
-    if durs:
+    def kernel_line(tag, name, flops):
+        durs = prof.get(tag, [])
+        if not durs:
+            return None
         avg_ms = sum(durs) / len(durs)
-        flops = 2.0 * n_valid * D * (2 * D)                  # algorithmic: 4*D^2 per valid cell
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        tr_path = os.path.join(ROOT, "profiles", "pmc_moment_fwd.json")
-        if os.path.exists(tr_path) and args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
-            try:                                            # PMC traffic was collected on exactly this workload
-                traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<CatMat,PlainMat,EpMomentOut> (moment-unit forward)",
-                    "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": len(durs),
-                    "flops_per_launch": flops, "valid_cells_per_launch": n_valid}
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        return {"kernel": name, "achieved": ach, "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": avg_ms, "launches_timed": len(durs),
+                "flops_per_launch": flops}
+
+    # dominant kernels: the three moment-unit contractions (one launch each per layer per step), 4*D^2 FLOP per valid cell each
+    mu_flops = 2.0 * n_valid * D * (2 * D)
+    gemms = {"moment_fwd": kernel_line("moment_fwd", "gemm_nt_kernel<CatMat,PlainMat,EpMomentOut>  mu = [x1|mean_c f_c] Wcat^T", mu_flops),
+             "moment_dx": kernel_line("moment_dx", "gemm_nt_kernel<PlainMat,PlainMat,EpSplitStore>  dX = dmu Wcat", mu_flops),
+             "moment_dw": kernel_line("moment_dw", "gemm_tn_kernel<PlainMat,CatMat>  dWcat = dmu^T [x1|mean_c f_c]", mu_flops)}
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_moment.json")
+    if os.path.exists(pmc_path) and args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
+        try:                                                # PMC traffic (rocprofv3 --pmc, gfx950 corrections) of exactly this workload
+            pmc = json.load(open(pmc_path))
+        except Exception:
+            pmc = {}
+    elif args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
+        try:                                                # round-1 file: forward contraction only
+            pmc = {"moment_fwd": json.load(open(os.path.join(ROOT, "profiles", "pmc_moment_fwd.json")))}
+        except Exception:
+            pmc = {}
+    roofline = None
+    if gemms["moment_fwd"]:
+        g = gemms["moment_fwd"]
+        roofline = {"bound": "mfma", "kernel": g["kernel"], "achieved": g["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": g["frac"], "traffic": pmc.get("moment_fwd", {}).get("hbm_bytes_per_launch"), "avg_launch_ms": g["avg_launch_ms"],
+                    "launches_timed": g["launches_timed"], "flops_per_launch": mu_flops, "valid_cells_per_launch": n_valid,
+                    "algorithmic_bytes_per_launch": 4.0 * n_valid * 4 * D}
+        for k in ("moment_dx", "moment_dw"):
+            if gemms[k]:
+                gemms[k]["traffic"] = pmc.get(k, {}).get("hbm_bytes_per_launch")
+        roofline["moment_gemms"] = {k: v for k, v in gemms.items() if v}
+        attn = {}
+        # attention core: HBM-side view.  fwd reads chat, writes cc (+ mean); bwd reads chat + 1-2 gradients, writes dchat
+        rows = n_valid * C
+        for tag, nbytes in (("attn_fwd", 4.0 * dl * (2 * rows + n_valid)), ("attn_bwd", 4.0 * dl * (3 * rows + n_valid))):
+            durs = prof.get(tag, [])
+            if durs:
+                avg_ms = sum(durs) / len(durs)
+                attn[tag] = {"avg_launch_ms": avg_ms, "launches_timed": len(durs), "algorithmic_bytes_per_launch": nbytes,
+                             "achieved_GBs": nbytes / (avg_ms * 1e-3) / 1e9, "frac_hbm": nbytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        roofline["attention_core"] = attn
+        fa, fe, ba = step_work(C, D, dl, Nq, layers)
+        t_fb = elapsed_fb / args.steps
+        per_rank_valid = n_valid_total / world
+        roofline["step"] = {"valid_cells": n_valid_total, "flops_algorithmic_per_cell": fa, "flops_executed_per_cell": fe,
+                            "bytes_algorithmic_per_cell": ba, "timed_on": "ms_fwd_bwd",
+                            "frac_mfma": per_rank_valid * fa / t_fb / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                            "frac_mfma_executed": per_rank_valid * fe / t_fb / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                            "frac_hbm": per_rank_valid * ba / t_fb / 1e9 / PEAK_HBM_GBS,
+                            "bound": "mfma (fp32: ~110 FLOP/B is above the 20 FLOP/B ridge)"}
 
     if rank == 0:
         total_B = B * world
         ms = elapsed / args.steps * 1e3
+        exchange = ""
+        if world_seen > 1 or backend is not None:
+            lib_name = {"nccl": "RCCL (torch backend nccl)", "gloo": "gloo (host-staged; NOT RCCL)"}.get(backend, str(backend))
+            exchange = f"+gradient all-reduce (DDP) over {lib_name}, process group of {world_seen}"
         out = {
             "metric": "proposals/sec (fwd+bwd)", "value": total_B * L * L / (elapsed / args.steps), "unit": "proposals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_with_adam": None if args.no_optimizer else ms,
+            "ms_fwd_bwd": elapsed_fb / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"
-                                   + ("" if args.no_optimizer else "+Adam") + ("+RCCL grad all-reduce (DDP)" if world > 1 else ""),
+                                   + ("" if args.no_optimizer else "+Adam") + exchange,
                        "global_batch": total_B, "valid_cells_per_step": n_valid_total,
-                       "valid_cells_per_s": n_valid_total / (elapsed / args.steps), "parallelism": f"dp{world}",
+                       "valid_cells_per_s": n_valid_total / (elapsed / args.steps), "parallelism": f"dp{world}", "dist_backend": backend, "dist_world_size": world_seen,
+                       "ddp_overrides": getattr(model, "ddp_overrides", None),
                        "final_loss": float(loss.item())},
             "roofline": roofline,
         }

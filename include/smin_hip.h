@@ -41,6 +41,17 @@ int smin_abi_version(void);
  * Process-wide; returns 0 or -1 for an unknown mode. */
 int smin_set_gemm_mode(int mode);
 int smin_get_gemm_mode(void);
+/* Launch timing for benchmarks: while enabled, chosen launches inside the entry points below are bracketed by HIP events
+ * recorded on the stream the launch goes to (tags: SMIN_PROF_*).  smin_prof_enable(1) clears earlier records;
+ * smin_prof_read waits for the recorded events, writes up to `cap` (tag, milliseconds) pairs in launch order and returns
+ * how many it wrote (or a negative code).  Off by default; costs two event records per tagged launch when on. */
+#define SMIN_PROF_MOMENT_FWD 1   /* moment unit, forward contraction   mu = [x1 | mean_c f_c] Wcat^T          */
+#define SMIN_PROF_MOMENT_DX 2    /* moment unit, input gradient        dX = dmu Wcat                            */
+#define SMIN_PROF_MOMENT_DW 3    /* moment unit, weight gradient       dWcat = dmu^T [x1 | mean_c f_c]         */
+#define SMIN_PROF_ATTN_FWD 4     /* content attention core, forward                                             */
+#define SMIN_PROF_ATTN_BWD 5     /* content attention core, backward (all its launches)                         */
+int smin_prof_enable(int on);
+int smin_prof_read(int32_t* tags, float* ms, int cap);
 /* "gfx950" -- the only code object in the library */
 const char* smin_target_arch(void);
 /* bytes of scratch any single call below may need for N cells (C, D, dl, Nq, B as given) */

@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the N > 1 path of bench.py / training -- batch sharding + DDP gradient all-reduce.
-The HIP kernels cannot run here, so the model under DDP is the torch-only part of the drop-in (Backbone) with a
-per-sample-mean loss of the same form as the restated loss: averaged shard gradients must equal
-full-batch gradients, timings reduce with MAX, counts with SUM."""
+"""CPU, world_size 2, gloo: the N > 1 plumbing of bench.py / training -- batch sharding, the DDP wrapper, MAX / SUM
+reductions over ranks (vml_amd/distributed.py).  The product has no CPU path (every module forward raises on CPU tensors),
+so the network under DDP here is a stand-in torch module defined in this file, with a batch-mean-of-per-sample-means loss
+of the same form as the restated loss: averaged shard gradients must equal full-batch gradients.  The
+SMIN HIP path under DDP is tests/test_ddp_hip.py (-m gpu)."""
 import os
 import socket
 
@@ -18,6 +19,20 @@ def _free_port():
     return p
 
 
+class _StandIn(torch.nn.Module):
+    """Batch-independent stand-in with the hot path's input signature (video rows, mask, words, mask)."""
+
+    def __init__(self, din, d):
+        super().__init__()
+        self.v, self.q = torch.nn.Linear(din, d), torch.nn.Linear(300, d)
+        self.overlap_boundary, self.overlap_prep = True, True      # the flags distributed.wrap manages on SMIN
+
+    def forward(self, vf, vm, qf, qm):
+        fw = torch.tanh(self.q(qf)) * qm.float()
+        fs = fw.sum(1) / qm.float().sum(1).clamp(min=1)
+        return torch.tanh(self.v(vf)) * vm.float() * fs.unsqueeze(1), fs, fw
+
+
 def _loss(model, batch):
     f, fs, fw = model(batch["video_features"], batch["video_mask"], batch["query_features"], batch["query_mask"])
     per_sample = f.square().mean(dim=(1, 2)) + fs.abs().mean(dim=1) + fw.mean(dim=(1, 2))
@@ -32,12 +47,14 @@ def _worker(rank, world, port, q):
     D = models.vml_amd.distributed
     D.init(backend="gloo")
     torch.manual_seed(7)
-    model = models.Backbone(16, 32, 24, 6, 16)
+    model = _StandIn(24, 32)
     full = O.synthetic_batch(4, 16, 8, 6, 24, seed=3, with_labels=False)
-    ref = models.Backbone(16, 32, 24, 6, 16)
+    ref = _StandIn(24, 32)
     ref.load_state_dict(model.state_dict())
     _loss(ref, full).backward()
     net = D.wrap(model)
+    assert net is not model and model.ddp_overrides == {"overlap_prep": False} and model.overlap_boundary   # CPU gloo keeps the rest
+    assert D.describe() == ("gloo", 2)
     shard = D.shard_batch(full, rank, world)
     assert shard["video_features"].shape[0] == 2
     _loss(net, shard).backward()

@@ -85,10 +85,36 @@ def test_library_exports_every_declared_symbol():
 def test_product_path_fails_loudly_on_cpu():
     import models
     from oracle import smin_oracle as O
+    Err = models.vml_amd._lib.SminHipError
     m = models.SMIN(16, 8, 4, 32, 16, 1, 24, 5, 16)
-    b = O.synthetic_batch(2, 16, 8, 5, 24, with_labels=False)
-    with pytest.raises(models.vml_amd._lib.SminHipError, match="no CPU fallback"):
+    b = O.synthetic_batch(2, 16, 8, 5, 24)
+    with pytest.raises(Err, match="no CPU fallback"):
         m(*H.model_inputs(b))
+    # every stand-alone module seam as well: nothing of the surface computes on the host
+    D, dl, B, L, C, Nq = 32, 16, 2, 8, 4, 5
+    z = torch.zeros
+    seams = [
+        (models.VideoEncoder(16, D, 24), (b["video_features"], b["video_mask"])),
+        (models.QueryEncoder(5, 16), (b["query_features"], b["query_mask"])),
+        (models.Backbone(16, D, 24, 5, 16), (b["video_features"], b["video_mask"], b["query_features"], b["query_mask"])),
+        (models.ProposalGeneration(16, 8, 4), (z(B, 16, D), b["moment_mask"])),
+        (models.Attention(D), (z(B, L, D), z(B, Nq, D), z(B, Nq, D), b["query_mask"])),
+        (models.ContentAttention(dl), (z(B, L, L, C, dl), z(B, Nq, dl), z(B, Nq, dl), b["query_mask"])),
+        (models.ContentUnit(D, dl), (z(B, L, L, C, D), z(B, Nq, D), z(B, D), z(B, L, L, D), b["query_mask"], b["moment_mask"])),
+        (models.BoundaryUnit(D), (z(B, L, D), z(B, Nq, D), z(B, D), z(B, L, L, D), b["query_mask"], b["length_mask"])),
+        (models.MomentUnit(D), (z(B, L, L, C, D), z(B, L, L, D), z(B, L, D), b["moment_mask"])),
+        (models.SMI(D, dl), (z(B, L, L, C, D), z(B, L, L, D), z(B, L, D), z(B, Nq, D), z(B, D), b["query_mask"], b["length_mask"], b["moment_mask"])),
+        (models.Localization(D), (z(B, L, L, D), z(B, L, D), b["length_mask"], b["moment_mask"])),
+    ]
+    for mod, args in seams:
+        with pytest.raises(Err, match="no CPU fallback"):
+            mod(*args)
+    out = {k: torch.rand(B, L, L) if k == "pm" else torch.rand(B, L) for k in ("pm", "ps", "pe", "pa")}
+    with pytest.raises(Err, match="no CPU fallback"):
+        models.vml_amd.loss_fn(out["pm"], b["ym"], b["sm"], b["moment_mask"], out["ps"], b["ys"], b["ss"], out["pe"], b["ye"], b["se"],
+                               out["pa"], b["ya"], b["length_mask"])
+    with pytest.raises(Err, match="no CPU fallback"):
+        models.vml_amd.compute_ious(out["pm"], out["ps"], out["pe"], b["moment_mask"], b["sm"])
 
 
 def test_product_never_imports_the_oracle():
@@ -144,11 +170,11 @@ def test_loss_and_metric_restatements_match_oracle_and_golden():
     import models
     from oracle import smin_oracle as O
     cfg, sd, batch, out, _, loss_ref = H.split_tiny(H.load_npz("g1_r4"))
-    loss = models.vml_amd.loss_fn(out["pm"], batch["ym"], batch["sm"], batch["moment_mask"], out["ps"], batch["ys"], batch["ss"],
+    loss = models.vml_amd.loss_fn_torch(out["pm"], batch["ym"], batch["sm"], batch["moment_mask"], out["ps"], batch["ys"], batch["ss"],
                                   out["pe"], batch["ye"], batch["se"], out["pa"], batch["ya"], batch["length_mask"])
     assert abs(loss.item() - loss_ref) < 1e-6
     z = H.load_npz("g6_ious")
-    got = models.vml_amd.compute_ious(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))
+    got = models.vml_amd.compute_ious_torch(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))
     for k, v in zip(z["keys"], z["vals"]):
         assert got[str(k)] == float(v)
     assert got == O.compute_ious(*(torch.from_numpy(z[k]) for k in ("pm", "ps", "pe", "mm", "sm")))

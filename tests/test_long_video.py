@@ -1,0 +1,136 @@
+"""GPU: the long-video stress regime of BASELINE.json configs[4] (T_clip = 1024, 512 x 512 proposal map, r = T/L = 2).
+
+The reference cannot run this shape at all (models.py:88-98 would build a 4 GiB content matrix, :117 a 2 GiB-per-sample
+f_c), so parity is anchored in two ways: (a) the dense CPU oracle at the largest size it can hold -- T=512, L=256, r=2,
+B=1 with the full feature widths (f_c = 512 MB) -- forward scores and every parameter gradient; (b) at the full shape,
+size-independent properties: masked proposals exactly 0, scores in [0, 1], bitwise-deterministic outputs and gradients,
+batch independence, finite gradients, contiguous pm.  compute_ious is checked at L = 512 against its torch form."""
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LONG = (1024, 512, 4, 512, 128, 3, 500, 20, 256)        # T, L, C, D, dl, layers, Din, Nq, H
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import models
+    models.vml_amd._lib.load()
+    return torch.device("cuda:0")
+
+
+def _model(shape, sd, dev):
+    import models
+    T, L, C, D, dl, layers, Din, Nq, Hh = shape
+    m = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev)
+    m.load_state_dict(sd)
+    return m.to(dev)
+
+
+def _loss(out, b):
+    from vml_amd import loss_fn
+    pm, ps, pe, pa = out
+    return loss_fn(pm, b["ym"], b["sm"], b["moment_mask"], ps, b["ys"], b["ss"], pe, b["ye"], b["se"], pa, b["ya"], b["length_mask"])
+
+
+@pytest.mark.timeout(1500)
+def test_long_video_oracle_parity_L256(dev):
+    """Dense oracle at T=512, L=256, r=2 (empty clips, dropped frames), B=1, full widths: scores and all gradients."""
+    from oracle import smin_oracle as O
+    T, L, C, D, dl, layers, Din, Nq, Hh = shape = (512, 256, 4, 512, 128, 3, 500, 20, 256)
+    sd = O.formula_state_dict(H.smin_shapes(*shape), gain=1.3)
+    batch = O.synthetic_batch(2, T, L, Nq, Din, seed=31)
+    batch = {k: v[1:2] for k, v in batch.items()}                      # the ragged sample (odd index), alone: B = 1
+    assert 0 < int(batch["length_mask"].sum()) < L
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.smin_forward(sdg, dict(T=T, L=L, C=C), *H.model_inputs(batch))
+    l0 = O.loss_fn(ref[0], batch["ym"], batch["sm"], batch["moment_mask"], ref[1], batch["ys"], batch["ss"], ref[2], batch["ye"],
+                   batch["se"], ref[3], batch["ya"], batch["length_mask"])
+    l0.backward()
+    ref = [r.detach() for r in ref]
+    m = _model(shape, sd, dev)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    out = m(*H.model_inputs(b))
+    for name, got, want in zip(("pm", "ps", "pe", "pa"), out, ref):
+        err = (got.detach().cpu() - want).abs().max().item()
+        print("L=256", name, "max abs err", err, "spread", want.min().item(), want.max().item())
+        assert err < 1e-4, (name, err)                                 # north_star: 1e-3
+    loss = _loss(out, b)
+    assert abs(loss.item() - l0.item()) < 1e-4
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        g0 = sdg[k].grad
+        # + 1e-7: the key bias of a word attention shifts all scores of a row alike (softmax-invariant), its gradient is ~1e-9 noise
+        e = (p.grad.cpu() - g0).abs().max().item() / (g0.abs().max().item() + 1e-7 / 2e-3)
+        worst = max(worst, e)
+        assert e <= 2e-3, (k, e)
+    print("L=256 worst relative gradient error", worst)
+
+
+@pytest.mark.timeout(1500)
+def test_long_video_properties_full_shape(dev):
+    """T=1024, L=512, r=2 at B=2 (one full-length, one ragged sample): the shape the reference cannot build."""
+    from oracle import smin_oracle as O
+    T, L, C, D, dl, layers, Din, Nq, Hh = LONG
+    sd = O.formula_state_dict(H.smin_shapes(*LONG), gain=1.3)
+    batch = O.synthetic_batch(2, T, L, Nq, Din, seed=9)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    m = _model(LONG, sd, dev)
+    snaps = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        out = m(*H.model_inputs(b))
+        _loss(out, b).backward()
+        snaps.append(([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (out1, g1), (out2, g2) = snaps
+    pm = out1[0]
+    assert pm.shape == (2, L, L) and pm.is_contiguous()
+    for x, y in zip(out1, out2):
+        assert torch.equal(x, y)                                        # deterministic forward
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g2[k]), k                             # fixed-order reductions: deterministic gradients
+        assert g1[k].abs().max().item() > 0, k
+    assert pm[~b["moment_mask"]].abs().max().item() == 0.0              # masked proposals are exactly 0
+    for o in out1[1:]:
+        assert o[~b["length_mask"]].abs().max().item() == 0.0
+    assert all(((o >= 0) & (o <= 1)).all() for o in out1)
+    assert pm[b["moment_mask"]].std().item() > 1e-3                     # not a constant map
+    with torch.no_grad():
+        for s in (0, 1):                                                # batch independence
+            one = m(*[x[s:s + 1] for x in H.model_inputs(b)])
+            for x, y in zip(one, out1):
+                assert (x[0] - y[s]).abs().max().item() < 1e-5
+    del snaps, out1, out2, g1, g2
+    torch.cuda.empty_cache()
+
+
+def test_compute_ious_long_video(dev):
+    """utils.py:10-31 at L = 512 (262 144 proposals per sample): the one-kernel metric against its torch form."""
+    import models
+    g = torch.Generator().manual_seed(4)
+    B, L = 5, 512
+    lm = torch.ones(B, L, dtype=torch.bool)
+    lm[1, 300:] = False
+    lm[3, 17:] = False
+    mm = torch.triu(lm.unsqueeze(2) & lm.unsqueeze(1))
+    pm = torch.rand(B, L, L, generator=g) * mm
+    ps, pe = torch.rand(B, L, generator=g), torch.rand(B, L, generator=g)
+    sm = torch.rand(B, L, L, generator=g) * mm
+    args = [x.to(dev) for x in (pm, ps, pe, mm, sm)]
+    got = models.vml_amd.compute_ious(*args)
+    want = models.vml_amd.compute_ious_torch(*args)
+    assert got == want
+    assert got == models.vml_amd.compute_ious_torch(pm, ps, pe, mm, sm)
+    # small maps down to the five-proposal minimum use the same kernel (round 1 rejected L <= 2 and L = 196)
+    for L2 in (3, 196, 197):
+        lm2 = torch.ones(2, L2, dtype=torch.bool)
+        mm2 = torch.triu(lm2.unsqueeze(2) & lm2.unsqueeze(1))
+        a = [torch.rand(2, L2, L2, generator=g) * mm2, torch.rand(2, L2, generator=g), torch.rand(2, L2, generator=g), mm2,
+             torch.rand(2, L2, L2, generator=g) * mm2]
+        assert models.vml_amd.compute_ious(*(x.to(dev) for x in a)) == models.vml_amd.compute_ious_torch(*a)

@@ -18,6 +18,8 @@ SIGNATURES = {
     "smin_target_arch": [],
     "smin_set_gemm_mode": [_i],
     "smin_get_gemm_mode": [],
+    "smin_prof_enable": [_i],
+    "smin_prof_read": [_vp, _vp, _i],
     "smin_workspace_bytes": [_i] * 6,
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
     "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp, _vp],
@@ -135,6 +137,26 @@ def check(rc, name):
 
 def call(name, *args):
     check(getattr(load(), name)(*args), name)
+
+
+PROF_TAGS = {1: "moment_fwd", 2: "moment_dx", 3: "moment_dw", 4: "attn_fwd", 5: "attn_bwd"}
+
+
+def prof_enable(on=True):
+    """Bracket the tagged launches (include/smin_hip.h SMIN_PROF_*) with HIP events on their launch stream."""
+    check(load().smin_prof_enable(int(on)), "smin_prof_enable")
+
+
+def prof_read(cap=1 << 16):
+    """{tag name: [milliseconds per launch, in launch order]} of everything recorded since prof_enable(True)."""
+    tags, ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
+    n = load().smin_prof_read(tags, ms, cap)
+    if n < 0:
+        raise SminHipError(f"smin_prof_read failed with code {n}")
+    out = {}
+    for k in range(n):
+        out.setdefault(PROF_TAGS.get(tags[k], str(tags[k])), []).append(ms[k])
+    return out
 
 
 GEMM_MODES = {"f32": 0, "bf16x3": 1}

@@ -16,6 +16,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (!(cond)) return -1000 - __LINE__;                \
     } while (0)
 
+// benchmark launch timing (smin_prof_enable / smin_prof_read): HIP events on the launch stream around a scope
+namespace smin {
+extern volatile int g_prof_on;
+void prof_record(hipStream_t st, int tag, bool begin);
+struct ProfScope {
+    hipStream_t st; int tag; bool on;
+    ProfScope(hipStream_t s, int t) : st(s), tag(t), on(g_prof_on != 0) { if (on) prof_record(st, tag, true); }
+    ~ProfScope() { if (on) prof_record(st, tag, false); }
+};
+}  // namespace smin
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // chunking of each sample's cell range over workgroups.

@@ -12,6 +12,7 @@
 // them back coalesced -- fixed-order partial slabs keep everything deterministic.
 // (A first version used 32-row tiles on the 32x32x2 MFMA: its backward needed 426 registers, one wave per SIMD.)
 #include "content_attn.h"
+#include "smin_hip.h"
 
 namespace smin {
 
@@ -571,6 +572,7 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
     SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     SMIN_REQUIRE(cc || ccmean);
+    ProfScope prof((hipStream_t)stream, SMIN_PROF_ATTN_FWD);
     return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
 }
 
@@ -596,6 +598,7 @@ extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float
     const float* g = dcc; const float* g2 = nullptr; int per_cell = 0; float gscale = 1.0f;
     if (dcc && dccmean) g2 = dccmean;                               // both consumers: summed while the rows are loaded
     else if (!dcc) { g = dccmean; per_cell = 1; gscale = 1.0f / C; }
+    ProfScope prof(st, SMIN_PROF_ATTN_BWD);
     return launch_content_attn_bwd(st, chat, g, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq,
                                    per_cell, gscale, g2, 1.0f / C);
 }

@@ -83,6 +83,7 @@ extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const flo
     (void)B;
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
+    ProfScope prof(st, SMIN_PROF_MOMENT_FWD);
     if (!x1 || N == 0)
         return launch_gemm_nt(st, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
     return launch_gemm_nt(st, pair_cat(x1, fcmean, D), PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
@@ -118,8 +119,12 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
         // mask lookups the operand loads would otherwise wait for
         int rc;
         if (all_valid) {
-            rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
+            {
+                ProfScope prof(st, SMIN_PROF_MOMENT_DX);
+                rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
+            }
             if (rc) return rc;
+            ProfScope prof(st, SMIN_PROF_MOMENT_DW);
             if (x1) rc = launch_gemm_tn(st, PlainMat{dmu, D}, pair_cat(x1, fcmean, D), slab, bslab, N, D, 2 * D, sp);
             else rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
         } else {

@@ -1,10 +1,32 @@
 // Library identity, workspace sizing, slab reduction, dense<->packed layout helpers, stand-alone GEMM.
 #include "gemm.h"
 #include "smin_hip.h"
+#include <mutex>
+#include <vector>
 
 namespace smin {
 
 int g_gemm_mode = 0;
+
+// ---- launch timing (smin_prof_*): autograd runs backward on its own thread, hence the lock
+volatile int g_prof_on = 0;
+struct ProfRec { int tag; hipEvent_t e0, e1; bool closed; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+
+void prof_record(hipStream_t st, int tag, bool begin)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (begin) {
+        ProfRec r{tag, nullptr, nullptr, false};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, st);
+        g_prof.push_back(r);
+    } else {
+        for (size_t k = g_prof.size(); k-- > 0;)
+            if (g_prof[k].tag == tag && !g_prof[k].closed) { (void)hipEventRecord(g_prof[k].e1, st); g_prof[k].closed = true; break; }
+    }
+}
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int P)
 {
@@ -96,6 +118,32 @@ extern "C" int smin_set_gemm_mode(int mode)
 }
 extern "C" int smin_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" const char* smin_target_arch(void) { return "gfx950"; }
+
+extern "C" int smin_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on) {
+        for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        g_prof.clear();
+    }
+    g_prof_on = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int smin_prof_read(int32_t* tags, float* ms, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (n >= cap) break;
+        if (!r.closed) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -2;
+        tags[n] = r.tag; ms[n] = t; ++n;
+    }
+    return n;
+}
 
 extern "C" size_t smin_workspace_bytes(int N, int B, int C, int D, int dl, int Nq)
 {

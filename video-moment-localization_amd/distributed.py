@@ -1,10 +1,13 @@
 """Data-parallel plumbing for the train step: one process per GPU, batch sharded across ranks,
 gradients all-reduced by torch DistributedDataParallel over RCCL (backend "nccl" on ROCm; "gloo" in CPU tests).
 The hot path itself has no exchange step -- samples are independent -- so this is the only collective."""
+import logging
 import os
 
 import torch
 import torch.distributed as dist
+
+log = logging.getLogger("vml_amd.distributed")
 
 
 def env_world():
@@ -44,18 +47,31 @@ def wrap(model, device=None, bucket_cap_mb=8):
     (28-36 MB of fp32 gradients per step: SURVEY 5)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("SMIN_FORCE_DDP")):
         return model
+    changed = {}
     if dist.get_backend() == "gloo" and getattr(model, "overlap_boundary", False) and device is not None and device.type == "cuda":
         # gloo stages every bucket through the host and synchronises the streams a gradient touched: with the two-stream
         # step that serialises the whole backward pass (8x slower, measured); RCCL is unaffected
-        model.overlap_boundary = False
+        model.overlap_boundary = changed["overlap_boundary"] = False
     if getattr(model, "overlap_prep", False):
         # DDP creates every parameter's gradient accumulator on the stream it is constructed on; parameters that the step
         # touches only on the second stream then make the main stream wait at each accumulation (measured +0.7 ms over
         # keeping that work on the main stream; the boundary unit's overlap still pays)
-        model.overlap_prep = False
+        model.overlap_prep = changed["overlap_prep"] = False
+    model.ddp_overrides = changed                      # what wrap() switched off, for the caller to report
+    if changed:
+        log.warning("distributed.wrap (%s, world %d): set %s on the model", dist.get_backend(), dist.get_world_size(),
+                    ", ".join(f"{k}={v}" for k, v in changed.items()))
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+
+def describe():
+    """(backend, world size) of the default process group as the collective library reports them -- what a benchmark
+    line may claim about its gradient exchange."""
+    if not dist.is_initialized():
+        return None, 1
+    return dist.get_backend(), dist.get_world_size()
 
 
 def max_over_ranks(value, device):

@@ -10,21 +10,6 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 
-# bench.py sets RECORD_EVENTS to bracket chosen launches with HIP events on the launch stream
-RECORD_EVENTS = False
-KERNEL_EVENTS = []
-
-
-def _timed_call(tag, name, *args):
-    if not RECORD_EVENTS:
-        return call(name, *args)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    call(name, *args)
-    e.record()
-    KERNEL_EVENTS.append((tag, s, e))
-
-
 def _c(t):
     return None if t is None else t.contiguous()
 
@@ -451,7 +436,7 @@ class MomentUnitFn(Function):
         mu = torch.empty_like(fm)
         x1 = torch.empty_like(fm)                                     # f_b[i] * f_b[j], kept for the weight gradient
         call("smin_pair_product", stream(), ptr(fb), ptr(layout.cells), N, L, D, ptr(x1))
-        _timed_call("moment_unit_fwd", "smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu), ptr(x1))
+        call("smin_moment_unit_fwd", stream(), ptr(fcmean), ptr(fm), ptr(fb), ptr(layout.cells), N, B, L, D, ptr(Wcat), ptr(bcat), ptr(mu), ptr(x1))
         ctx.save_for_backward(fcmean, fb, Wcat, x1)
         ctx.layout = layout
         return mu, fcmean.view_as(fcmean)

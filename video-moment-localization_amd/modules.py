@@ -12,14 +12,33 @@ Inside ``SMIN.forward`` the L x L map lives in the packed valid-cell layout (cel
 Per-cell work and the whole boundary unit run in HIP (functional.py); the O(B*Nq*dl) word-side projections of the
 content unit and the backbone stay plain torch library calls.
 """
+import functools
 import math
 
 import torch
 import torch.nn as nn
 
+from ._lib import SminHipError
+
 from .cells import CellLayout
 from .functional import (VideoFuseFn, BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
                          ProposalMapFn, ProposalMeansFn, ScoreMapFn)
+
+
+def _hip_forward(fn):
+    """Every forward of this module surface runs on a HIP device only (there is no CPU path: a CPU tensor raises), with the
+    tensor's device made current for the call -- the C ABI launches on torch's current stream, so a model living on
+    cuda:N while another device is current (the reference's ctor accepts any ``device``) must not launch on the wrong
+    device's stream.  autograd restores the forward's device for the backward nodes by itself."""
+    @functools.wraps(fn)
+    def wrapper(self, x, *args, **kwargs):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise SminHipError(f"{type(self).__name__}.forward runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        if x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(self, x, *args, **kwargs)
+        return fn(self, x, *args, **kwargs)
+    return wrapper
 
 
 def _rows(mask):
@@ -36,10 +55,11 @@ class VideoEncoder(nn.Module):
         self.ve = nn.Linear(self.d0, self.d)
         self.pe = nn.Embedding(self.T, self.d)
 
+    @_hip_forward
     def forward(self, video_features, video_mask):
         vm = video_mask.float()
         pos = torch.arange(video_mask.shape[1], device=video_features.device)
-        if video_features.is_cuda and self.d0 % 4 == 0 and self.d % 4 == 0 and video_features.dtype == torch.float32:
+        if self.d0 % 4 == 0 and self.d % 4 == 0 and video_features.dtype == torch.float32:
             B, T, _ = video_features.shape                          # the projection on the library's MFMA engine
             y = LinearRowsFn.apply(self.ve.weight, self.ve.bias, None, None, 1, video_features.reshape(B * T, self.d0)).view(B, T, self.d)
         else:
@@ -73,6 +93,7 @@ class QueryEncoder(nn.Module):
         self.max_query_length, self.lstm_hidden_size = max_query_length, lstm_hidden_size
         self.lstm = nn.LSTM(input_size=300, hidden_size=lstm_hidden_size, num_layers=2, bidirectional=True, batch_first=True)
 
+    @_hip_forward
     def forward(self, query_features, query_mask):
         """Same result as the reference's pack_padded_sequence / pad_packed_sequence round trip, but on padded
         tensors with the lengths kept on the device: the reference copies them to the host here
@@ -82,7 +103,7 @@ class QueryEncoder(nn.Module):
         B, Nq, _ = query_features.shape
         H = self.lstm_hidden_size
         length = query_mask.reshape(B, -1).sum(1).long()
-        if query_features.is_cuda and self.fused_lstm and H <= 256 and H % 4 == 0:
+        if self.fused_lstm and H <= 256 and H % 4 == 0:
             # one HIP launch per layer runs the whole recurrence, both directions, lengths honoured in-kernel
             # (bilstm.hip): the library path below is ~600 launches of a few microseconds each per train step
             x, len32 = query_features, length.to(torch.int32)
@@ -106,7 +127,7 @@ class QueryEncoder(nn.Module):
 
         # The two directions of a layer are independent chains of Nq tiny, latency-bound kernels: on the GPU they run
         # on two HIP streams side by side (autograd replays each chain's backward on the stream of its forward).
-        side = _side_stream(x.device) if x.is_cuda else None
+        side = _side_stream(x.device)
         for layer in range(2):
             if side is None:
                 outs = [run(layer, "", x), run(layer, "_reverse", x)]
@@ -143,10 +164,11 @@ class Backbone(nn.Module):
         self.videoencoder = VideoEncoder(T, d, input_video_dim, device)
         self.queryencoder = QueryEncoder(max_query_length, lstm_hidden_size)
 
+    @_hip_forward
     def forward(self, video_features, video_mask, query_features, query_mask):
         fs, fw = self.queryencoder(query_features, query_mask)
         ve = self.videoencoder
-        if (video_features.is_cuda and video_features.dtype == torch.float32 and ve.d0 % 4 == 0 and ve.d % 4 == 0
+        if (video_features.dtype == torch.float32 and ve.d0 % 4 == 0 and ve.d % 4 == 0
                 and video_features.shape[1] <= ve.pe.weight.shape[0]):
             # projection + position embedding + mask + Hadamard product with f_s in one contraction (video_encoder.hip)
             B, T, _ = video_features.shape
@@ -183,6 +205,7 @@ class ProposalGeneration(nn.Module):
     def forward_packed(self, f, layout):
         return ProposalMapFn.apply(f, layout, self.T, self.L, self.C)
 
+    @_hip_forward
     def forward(self, f, moment_mask):
         layout = CellLayout.from_mask(moment_mask)
         fc, fm, fb = self.forward_packed(f, layout)
@@ -209,6 +232,7 @@ class Attention(nn.Module):
         self.W_q = nn.Linear(D, D)
         self.W_k = nn.Linear(D, D)
 
+    @_hip_forward
     def forward(self, query, key, value, mask=None):
         out, _ = _word_attention(self.W_q, self.W_k, query, key, value, mask, self.D)
         return out
@@ -227,6 +251,7 @@ class BoundaryUnit(nn.Module):
         return BoundaryUnitFn.apply(f_b, f_w, f_s, hbar, at.W_q.weight, at.W_q.bias, at.W_k.weight, at.W_k.bias,
                                     _rows(query_mask), length_mask.float(), layout)
 
+    @_hip_forward
     def forward(self, f_b, f_w, f_s, f_m, query_mask, length_mask):
         B, L = f_m.shape[:2]
         layout = CellLayout.all_cells(torch.ones(B, L, L, dtype=torch.bool, device=f_m.device))
@@ -244,6 +269,7 @@ class ContentAttention(nn.Module):
         self.W_q = nn.Linear(D, D)
         self.W_k = nn.Linear(D, D)
 
+    @_hip_forward
     def forward(self, query, key, value, mask=None):
         B = query.shape[0]
         q = query.reshape(B, -1, query.shape[-1])
@@ -279,6 +305,7 @@ class ContentUnit(nn.Module):
         return ContentUnitFn.apply(fc, hbar, self.linear_c_hat.weight, self.linear_c_hat.bias, Mq, uq, what, shat, qm,
                                    self.linear_c.weight, self.linear_c.bias, layout, fcmean_in)
 
+    @_hip_forward
     def forward(self, f_c, f_w, f_s, f_m, query_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
         hbar = GateFn.apply(layout.pack(f_m), f_s, layout)[0]
@@ -305,6 +332,7 @@ class MomentUnit(nn.Module):
         Wcat, bcat = self.cat_weights()
         return MomentUnitFn.apply(fcmean, fm, f_b, Wcat, bcat, layout)[0]
 
+    @_hip_forward
     def forward(self, f_c, f_m, f_b, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
         mu = self.forward_packed(layout.pack(f_c).mean(dim=1), layout.pack(f_m), f_b, layout)
@@ -330,6 +358,7 @@ class SMI(nn.Module):
         mu = self.moment_unit.forward_packed(cumean, fm_res, bu, layout)
         return cu, mu, bu, cumean
 
+    @_hip_forward
     def forward(self, f_c, f_m, f_b, f_w, f_s, query_mask, length_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
         cu, mu, bu, _ = self.forward_packed(layout.pack(f_c), layout.pack(f_m), f_b, f_w, f_s, query_mask, length_mask, layout)
@@ -356,6 +385,7 @@ class Localization(nn.Module):
                                     length_mask.float(), layout)
         return pm, psea[0], psea[1], psea[2]
 
+    @_hip_forward
     def forward(self, f_m, f_b, length_mask, moment_mask):
         layout = CellLayout.all_cells(moment_mask)
         return self.forward_packed(layout.pack(f_m), f_b, length_mask, layout)
@@ -472,11 +502,13 @@ class SMIN(nn.Module):
             fb = bu
         return self.localization.forward_packed(fm, fb, length_mask, layout)
 
+    @_hip_forward
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
         f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
         layout = pending.finish()                                  # the only host sync of a step; hidden behind the backbone
-        if self.content_stream and self.dl < self.D and 2 <= self.C <= 4 and layout.all_valid and f.is_cuda:
+        if (self.content_stream and self.dl < self.D and 2 <= self.C <= 4 and layout.all_valid
+                and len(self.smis) <= 8 and len(self.smis) * self.dl <= 2048):    # limits of the clip-window-means launch
             return self._forward_stream(f, fs, fw, query_mask, length_mask, layout)
         fc, fm, fb = self.pgm.forward_packed(f, layout)
         fcmean = fm                                                # mean_c fc: the map's f_m, then each layer's clip mean

@@ -1,6 +1,7 @@
 """Caller-side pieces of the reference that the train step needs: the loss and the
-R@n/IoU metric, restated so that the unmodified training loop becomes runnable.  Plain torch; they run
-on whatever device the scores live on."""
+R@n/IoU metric, restated so that the unmodified training loop becomes runnable.  ``loss_fn`` / ``compute_ious`` are the
+product entry points (HIP kernels, HIP tensors only); ``*_torch`` are the same formulas as plain torch ops, kept under their
+own names as a second restatement the tests compare against -- nothing routes to them silently."""
 import torch
 import torch.nn.functional as F
 
@@ -26,27 +27,24 @@ def loss_fn_torch(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, lengt
             + bce_loss(pe, ye, se, length_mask) + 0.5 * bce_loss(pa, ya, None, length_mask))
 
 
+def _require_hip(t, what):
+    if not t.is_cuda:
+        from ._lib import SminHipError
+        raise SminHipError(f"{what} runs on a HIP device only (got a CPU tensor); there is no CPU fallback -- "
+                           f"the plain-torch restatement is available under the explicit name {what}_torch")
+
+
 def loss_fn(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask):
-    """reference main.py:110-116 (same argument order).  On a HIP device this is one fused forward and one fused
-    backward kernel (functional.LossFn) instead of ~40 element-wise launches; elsewhere the torch restatement."""
-    if pm.is_cuda:
-        from .functional import LossFn
+    """reference main.py:110-116 (same argument order): one fused forward and one fused backward kernel
+    (functional.LossFn, csrc/loss.hip) instead of ~40 element-wise launches.  HIP tensors only."""
+    _require_hip(pm, "loss_fn")
+    from .functional import LossFn
+    with torch.cuda.device(pm.device):
         return LossFn.apply(pm, ps, pe, pa, ym, sm, moment_mask, ys, ss, ye, se, ya, length_mask)
-    return loss_fn_torch(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask)
 
 
-def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
-    """reference utils.py:10-31 with a single host sync (the reference syncs once per (n, m) pair).  With the
-    reference's default n / m on a HIP device the whole metric is one kernel (csrc/metrics.hip)."""
-    if pm.is_cuda and tuple(n) == (1, 5) and tuple(m) == (0.1, 0.3, 0.5, 0.7) and pm.shape[1] <= 196:
-        from ._lib import call, ptr, stream
-        B, L = ps.shape
-        pm_, ps_, pe_, sm_ = (x.detach().float().contiguous() for x in (pm, ps, pe, sm))
-        mm_ = (moment_mask if moment_mask.dtype in (torch.bool, torch.uint8) else moment_mask != 0).contiguous()
-        counts, ws = pm_.new_empty(8), pm_.new_empty((B, 8))
-        call("smin_compute_ious", stream(), ptr(pm_), ptr(ps_), ptr(pe_), ptr(mm_), ptr(sm_), B, L, ptr(counts), ptr(ws))
-        vals = counts.tolist()
-        return {f"R@{n_}, IoU={m_}": vals[a * 4 + c] for a, n_ in enumerate(n) for c, m_ in enumerate(m)}
+def compute_ious_torch(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
+    """reference utils.py:10-31 as plain torch ops with a single host sync (the reference syncs once per (n, m) pair)."""
     score = pm * torch.sqrt(ps.unsqueeze(2)) * torch.sqrt(pe.unsqueeze(1)) * moment_mask
     B = score.shape[0]
     _, top = score.reshape(B, -1).topk(k=max(n), dim=1)
@@ -54,3 +52,21 @@ def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
     counts = torch.stack([((ious[:, :n_] > m_).sum(dim=1) > 0).sum() for n_ in n for m_ in m]).tolist()
     keys = [f"R@{n_}, IoU={m_}" for n_ in n for m_ in m]
     return {k: float(v) for k, v in zip(keys, counts)}
+
+
+def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
+    """reference utils.py:10-31 on the device.  With the reference's default n / m the whole metric is one kernel
+    (csrc/metrics.hip) and one host read, for any L -- the 512 x 512 long-video map included.  Other (n, m), or a map
+    with fewer than five proposals (where the reference's topk raises), take the torch form on the device."""
+    _require_hip(pm, "compute_ious")
+    if tuple(n) == (1, 5) and tuple(m) == (0.1, 0.3, 0.5, 0.7) and pm.shape[1] * pm.shape[2] >= 5:
+        from ._lib import call, ptr, stream
+        B, L = ps.shape
+        pm_, ps_, pe_, sm_ = (x.detach().float().contiguous() for x in (pm, ps, pe, sm))
+        mm_ = (moment_mask if moment_mask.dtype in (torch.bool, torch.uint8) else moment_mask != 0).contiguous()
+        counts, ws = pm_.new_empty(8), pm_.new_empty((B, 8))
+        with torch.cuda.device(pm.device):
+            call("smin_compute_ious", stream(), ptr(pm_), ptr(ps_), ptr(pe_), ptr(mm_), ptr(sm_), B, L, ptr(counts), ptr(ws))
+        vals = counts.tolist()
+        return {f"R@{n_}, IoU={m_}": vals[a * 4 + c] for a, n_ in enumerate(n) for c, m_ in enumerate(m)}
+    return compute_ious_torch(pm, ps, pe, moment_mask, sm, n, m)
