@@ -6,16 +6,14 @@
 
 namespace smin {
 
-constexpr int ATTN_SPLITS = 16;     // row-range splits per sample of the word-gradient reduction (x 4 waves)
-
-int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
+int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                             float* cc_rows, float* cc_mean, int dl, int Nq);
 
-// scratch floats needed by launch_content_attn_bwd for M = N*C rows
-size_t content_attn_bwd_ws_floats(int M, int B, int dl);
+// scratch floats needed by launch_content_attn_bwd for N cells (partial slabs of the word-side gradients)
+size_t content_attn_bwd_ws_floats(int N, int B, int dl);
 
-int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
+int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                             float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
                             const float* dmean2 /* nullable [N][dl]: a second, per-cell gradient added as dmean2 * mscale */, float mscale);

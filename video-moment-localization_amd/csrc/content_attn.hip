@@ -7,16 +7,27 @@
 //   P          = softmax over words                  in-register: 8 values per lane + two cross-lane exchanges
 //   a^T[d][n]  = sum_w what[w][d] P^T[w][n]         MFMA  A = what^T (LDS), B = the P accumulator as is
 //   q, Z = q q^T over the 4 clips of a cell, A = softmax(Z), cchat = A chat        VALU + DPP quad permutes
-// The backward pass mirrors it (dP^T = what . da^T and dchat^T += Mq^T . dS^T on MFMA) and streams da, dS and P
-// to HBM; the per-sample word-side reductions (dMq, dwhat, dshat, duq) are a second, MFMA "TN" kernel that reads
-// them back coalesced -- fixed-order partial slabs keep everything deterministic.
-// (A first version used 32-row tiles on the 32x32x2 MFMA: its backward needed 426 registers, one wave per SIMD.)
+// Work is cut into equal ranges of the packed cell list, one per resident workgroup; a workgroup stages the word-side
+// tiles (K/V: Mq, what) of a sample once per range segment (a range rarely crosses a sample boundary) -- not once per
+// 64-cell chunk, which made the staging, not the attention, the cost of the first version.
+// Words live in LDS in "slot" order: slot s = 16b + 4kg + r holds word 16b + 4r + kg, so that accumulator register r of
+// a score block (slots 16b + 4kg + r over the four lane groups kg) is the contiguous word group 16b + 4r .. + 3: the
+// contractions over words (a = P what, dchat += dS Mq) then skip whole MFMA steps past Nq (20 words: 5 steps, not 8).
+// The backward pass mirrors the forward (dP^T = what . da^T and dchat^T += Mq^T . dS^T on MFMA) and reduces the
+// per-sample word-side gradients in the same launch: the eight waves of a workgroup deposit the da / dS / P rows of a
+// round (8 tiles = 128 rows) in LDS and then contract them over the rows on the 32x32x2 MFMA
+// (dMq = dS^T chat, dwhat = P^T da, dshat = colsum da, duq = colsum dS), each wave owning one 32 x 32 block of the result.
+// da, dS and P never reach HBM; per-(range, sample) partial slabs are summed in fixed order by a small second launch.
+// (History: 32-row tiles on the 32x32x2 MFMA needed 426 registers in the backward; 16-row tiles with a separate
+// word-gradient kernel re-read 0.5 GB of da / dS / P per launch.)
 #include "content_attn.h"
 #include "smin_hip.h"
+#include <stdlib.h>
 
 namespace smin {
 
-constexpr int LDW = 36;                                       // row stride of the transposed [d][w] LDS images
+constexpr int LDW = 36;                                       // row stride of the transposed [d][slot] LDS image
+constexpr int LDP = 36;                                       // row stride of the dS / P round tiles [row][slot]
 
 template <int CTRL>
 __device__ __forceinline__ float qperm(float v) {             // quad permute (DPP): neighbour lane j ^ o
@@ -48,44 +59,8 @@ __device__ __forceinline__ void fmac_nb_sum(float& acc, float x, float y1, float
 }
 
 __device__ __forceinline__ int wmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// LDS carve (floats).  sM/sW: [32][DL+4] word-major; sMT/sWT: [DLP][36] feature-major (DLP = DL rounded to 32).
-template <int DL>
-struct AttnLds {
-    static constexpr int LDM = DL + 4;
-    static constexpr int DLP = (DL + 31) / 32 * 32;
-    float *sM, *sW, *sMT, *sWT, *sS, *sU, *sQ;
-    __device__ AttnLds(float* base, bool bwd) {
-        sM = base; sWT = sM + 32 * LDM; sS = sWT + DLP * LDW; sU = sS + DL; sQ = sU + 32;
-        sW = sQ + 32; sMT = sW + (bwd ? 32 * LDM : 0);
-    }
-    static size_t bytes(bool bwd) { return sizeof(float) * (size_t)(32 * LDM + DLP * LDW + DL + 64 + (bwd ? 32 * LDM + DLP * LDW : 0)); }
-};
-
-template <int DL>
-__device__ __forceinline__ void stage_sample(const AttnLds<DL>& s, bool bwd, const float* Mq, const float* uq, const float* what,
-                                             const float* shat, const float* qmask, int b, int dl, int Nq)
-{
-    constexpr int LDM = AttnLds<DL>::LDM, DLP = AttnLds<DL>::DLP;
-    const int t = threadIdx.x;
-    for (int idx = t; idx < 32 * LDM; idx += 256) {
-        const int w = idx / LDM, d = idx % LDM;
-        const bool ok = w < Nq && d < dl;
-        s.sM[idx] = ok ? Mq[((size_t)b * Nq + w) * dl + d] : 0.f;
-        if (bwd) s.sW[idx] = ok ? what[((size_t)b * Nq + w) * dl + d] : 0.f;
-    }
-    for (int idx = t; idx < DLP * LDW; idx += 256) {
-        const int d = idx / LDW, w = idx % LDW;
-        const bool ok = w < Nq && d < dl;
-        s.sWT[idx] = ok ? what[((size_t)b * Nq + w) * dl + d] : 0.f;
-        if (bwd) s.sMT[idx] = ok ? Mq[((size_t)b * Nq + w) * dl + d] : 0.f;
-    }
-    for (int d = t; d < DL; d += 256) s.sS[d] = d < dl ? shat[(size_t)b * dl + d] : 0.f;
-    if (t < 32) {
-        s.sU[t] = t < Nq ? uq[(size_t)b * Nq + t] : 0.f;
-        s.sQ[t] = t < Nq ? qmask[(size_t)b * Nq + t] : 0.f;
-    }
-}
+// word held by LDS slot s (and back: the map is an involution on each block of 16)
+__device__ __host__ __forceinline__ int slot_word(int s) { return (s & 16) + 4 * (s & 3) + ((s >> 2) & 3); }
 
 // per-lane geometry of a tile
 struct RowGeom {
@@ -96,20 +71,34 @@ struct RowGeom {
 };
 // ---- 16-row tiles on v_mfma_f32_16x16x4_f32 ---------------------------------------------------------------------
 // Accumulator layout of the 16x16x4 MFMA: register r of lane (n, kg) is element [4*kg + r][n], so
-//   S^T block b (words 16b .. 16b+15): lane holds words 16b + 4kg + r           -> P[4b + r]
+//   S^T block b (slots 16b .. 16b+15): lane holds slots 16b + 4kg + r            -> P[4b + r]
 //   a^T block j (features 16j .. 16j+15): lane holds features 16j + 4kg + r      -> aligned with ch[j][r]
-// and the P / dS accumulators feed the next MFMA as B operands without any data movement.  The backward fits 204
-// registers -> two waves per SIMD; a row's 16-byte loads of four neighbouring lanes form 64-byte segments.
+// and the P / dS accumulators feed the next MFMA as B operands without any data movement.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float kg_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
-__device__ __forceinline__ float kg_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+// all-reduce over the four lane groups kg (lanes n, n+16, n+32, n+48) in registers: gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange 16- and 32-lane rows without the LDS crossbar a __shfl_xor goes through.  Every lane ends with
+// the same bits: (r0 op r1) op (r2 op r3).
+__device__ __forceinline__ float kg_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float kg_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 
+// tile of cells n0 .. n0+3 of a segment ending at n_end (n_end >= 1); lanes past the segment (or every lane, when the tile
+// itself lies past it) are padding: ok = false, loads clamped to the segment's last cell
 __device__ __forceinline__ RowGeom row_geom16(const int* cells, int n0, int n_end, int C, int lane) {
     const int j = lane & 15, cell = n0 + (j >> 2), c = j & 3;
     RowGeom g;
     g.ok = cell < n_end && c < C;
-    const int cc = g.ok ? cell : n0;
+    const int cc = g.ok ? cell : n_end - 1;
     g.row = cc * C + (g.ok ? c : 0);
     g.m = g.ok ? (float)cells[4 * (size_t)cc + 3] : 0.f;
 #pragma unroll
@@ -117,30 +106,38 @@ __device__ __forceinline__ RowGeom row_geom16(const int* cells, int n0, int n_en
     return g;
 }
 
+// raw row loads (unconditional; masked when consumed)
 template <int DL>
-__device__ __forceinline__ void load_rows16(float (&v)[DL / 16][4], const float* src, const RowGeom& g, int dl, int kg) {
+__device__ __forceinline__ void fetch_rows16(float4 (&v)[DL / 16], const float* src, int row, int dl, int kg) {
+#pragma unroll
+    for (int j = 0; j < DL / 16; ++j) v[j] = ldg4(src + (size_t)row * dl + min(16 * j + 4 * kg, dl - 4));
+}
+template <int DL>
+__device__ __forceinline__ void mask_rows16(float (&v)[DL / 16][4], const float4 (&x)[DL / 16], bool rok, int dl, int kg) {
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
-        const int d = 16 * j + 4 * kg;
-        const float4 x = ldg4(src + (size_t)g.row * dl + min(d, dl - 4));
-        const bool ok = g.ok && d < dl;
-        v[j][0] = ok ? x.x : 0.f; v[j][1] = ok ? x.y : 0.f; v[j][2] = ok ? x.z : 0.f; v[j][3] = ok ? x.w : 0.f;
+        const bool ok = rok && 16 * j + 4 * kg < dl;
+        v[j][0] = ok ? x[j].x : 0.f; v[j][1] = ok ? x[j].y : 0.f; v[j][2] = ok ? x[j].z : 0.f; v[j][3] = ok ? x[j].w : 0.f;
     }
 }
 
-// P[4b + r] = softmax over words of row n, word 16b + 4kg + r
-template <int DL>
-__device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch)[DL / 16][4], const AttnLds<DL>& s, int Nq, float scale, int lane)
+// P[4b + r] = softmax over words of row n, slot 16b + 4kg + r.  sM: [32 slots][LDM] (A operand: lane l15 = slot in block)
+// WS = number of 4-word contraction steps the kernel is built for (>= ceil(Nq / 4)): compile-time, so that no MFMA sits
+// behind a branch on Nq (hipcc turns `if (Nq > ..) mfma` into a basic block per MFMA and stops scheduling across them).
+// Slots past Nq hold zeros in LDS and get P = 0, so computing a step that is not needed adds exact zeros.
+template <int DL, int WS>
+__device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch)[DL / 16][4], const float* sM, const float* sU, const float* sQ,
+                                                 int Nq, float scale, int lane)
 {
-    constexpr int LDM = AttnLds<DL>::LDM;
+    constexpr int LDM = DL + 4;
     const int l15 = lane & 15, kg = lane >> 4;
     f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
-        const float4 a0 = ldg4(s.sM + l15 * LDM + 16 * j + 4 * kg);
+        const float4 a0 = ldg4(sM + l15 * LDM + 16 * j + 4 * kg);
         S0 = mfma16(a0.x, ch[j][0], S0); S0 = mfma16(a0.y, ch[j][1], S0); S0 = mfma16(a0.z, ch[j][2], S0); S0 = mfma16(a0.w, ch[j][3], S0);
-        if (Nq > 16) {
-            const float4 a1 = ldg4(s.sM + (16 + l15) * LDM + 16 * j + 4 * kg);
+        if (WS > 4) {
+            const float4 a1 = ldg4(sM + (16 + l15) * LDM + 16 * j + 4 * kg);
             S1 = mfma16(a1.x, ch[j][0], S1); S1 = mfma16(a1.y, ch[j][1], S1); S1 = mfma16(a1.z, ch[j][2], S1); S1 = mfma16(a1.w, ch[j][3], S1);
         }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -148,9 +145,10 @@ __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int w = 16 * (r >> 2) + 4 * kg + (r & 3);
-        float v = ((r < 4 ? S0[r & 3] : S1[r & 3]) + s.sU[w]) * scale;
-        const float qm = s.sQ[w];
+        const int sl = 16 * (r >> 2) + 4 * kg + (r & 3);          // slot; its word is 16b + 4r + kg
+        const int w = 16 * (r >> 2) + 4 * (r & 3) + kg;
+        float v = ((r < 4 ? S0[r & 3] : S1[r & 3]) + sU[sl]) * scale;
+        const float qm = sQ[sl];
         v = (qm == 0.f) ? -1e9f : v * qm;                         // models.py:216-218
         v = (w < Nq) ? v : -INFINITY;
         P[r] = v;
@@ -166,33 +164,51 @@ __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch
     for (int r = 0; r < 8; ++r) P[r] *= inv;
 }
 
-// a^T block j: acc[r] = a[n][16j + 4kg + r] = sum_w what[w][16j + 4kg + r] P[n][w]
-template <int DL>
-__device__ __forceinline__ f32x4v attend_tile16(int j, const float (&P)[8], const AttnLds<DL>& s, int Nq, int lane)
+// out^T block j: acc[r] += sum_slots X[slot][16j + 4kg' ...]: the contraction over words with the word operand read from the
+// transposed image sXT [feature][LDW] (one b128 read feeds the four steps of a slot block).  Steps whose word group
+// 16b + 4r .. 16b + 4r + 3 lies past Nq are skipped.
+template <int WS>
+__device__ __forceinline__ f32x4v words_tile16_T(f32x4v acc, int j, const float (&V)[8], const float* sXT, int lane)
 {
     const int l15 = lane & 15, kg = lane >> 4;
-    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        if (16 * b < Nq) {
-            const float4 w4 = ldg4(s.sWT + (16 * j + l15) * LDW + 16 * b + 4 * kg);
-            acc = mfma16(w4.x, P[4 * b], acc); acc = mfma16(w4.y, P[4 * b + 1], acc);
-            acc = mfma16(w4.z, P[4 * b + 2], acc); acc = mfma16(w4.w, P[4 * b + 3], acc);
+        if (4 * b < WS) {
+            const float4 w4 = ldg4(sXT + (16 * j + l15) * LDW + 16 * b + 4 * kg);
+            acc = mfma16(w4.x, V[4 * b], acc);
+            if (4 * b + 1 < WS) acc = mfma16(w4.y, V[4 * b + 1], acc);
+            if (4 * b + 2 < WS) acc = mfma16(w4.z, V[4 * b + 2], acc);
+            if (4 * b + 3 < WS) acc = mfma16(w4.w, V[4 * b + 3], acc);
         }
     }
     return acc;
 }
+// the same contraction with the word operand read from the slot-major image sX [slot][LDM] (b32 reads, conflict-free: the
+// backward keeps only the slot-major images so that its round tiles fit in LDS)
+template <int LDM, int WS>
+__device__ __forceinline__ f32x4v words_tile16_S(f32x4v acc, int j, const float (&V)[8], const float* sX, int lane)
+{
+    const int l15 = lane & 15, kg = lane >> 4;
+    const float* base = sX + (4 * kg) * LDM + 16 * j + l15;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * b + r < WS) acc = mfma16(base[(16 * b + r) * LDM], V[4 * b + r], acc);
+    return acc;
+}
 
-template <int DL>
-__device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&ch)[DL / 16][4], const float (&P)[8],
-                                                 const AttnLds<DL>& s, const RowGeom& g, int Nq, float scale, int lane)
+// clip self-attention of a tile: Ao[o] = softmax_c'(q_c . q_c') * m for neighbour c' = c ^ o.  ATT(j) returns a^T block j.
+template <int DL, class ATT>
+__device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&ch)[DL / 16][4], const float* sS, const RowGeom& g, float scale,
+                                                 int lane, ATT att)
 {
     const int kg = lane >> 4;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
-        const f32x4v acc = attend_tile16<DL>(j, P, s, Nq, lane);
-        const float4 sh = ldg4(s.sS + 16 * j + 4 * kg);
+        const f32x4v acc = att(j);
+        const float4 sh = ldg4(sS + 16 * j + 4 * kg);
         const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -217,344 +233,472 @@ __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&c
     for (int o = 0; o < 4; ++o) Ao[o] *= inv;
 }
 
+// Stage one sample's word-side operands in slot order.  All global loads of the pass are issued before the first LDS store
+// (unconditional, clamped addresses; invalid slots / features become zeros).  NT threads.
+//   sM / sW : [32 slots][LDM]   (float4 along features)      sMT / sWT : [DLP features][LDW]   (slot-contiguous)
+template <int DL, int NT>
+__device__ __forceinline__ void stage_slot_major(float* sA, const float* src, int b, int dl, int Nq)
+{
+    constexpr int LDM = DL + 4, Q = DL / 4, TOT = 32 * Q, IT = (TOT + NT - 1) / NT;
+    float4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = min((int)threadIdx.x + NT * it, TOT - 1), sl = idx / Q, d = (idx % Q) * 4;
+        const int w = min(slot_word(sl), Nq - 1);
+        v[it] = ldg4(src + ((size_t)b * Nq + w) * dl + min(d, dl - 4));
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = (int)threadIdx.x + NT * it, sl = idx / Q, d = (idx % Q) * 4;
+        if (idx < TOT) stg4(sA + sl * LDM + d, f4sel(slot_word(sl) < Nq && d < dl, v[it]));
+    }
+}
+template <int DL, int NT>
+__device__ __forceinline__ void stage_feature_major(float* sT, const float* src, int b, int dl, int Nq)
+{
+    constexpr int Q = DL / 4, TOT = 32 * Q, IT = (TOT + NT - 1) / NT;
+    float4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {                             // slot fastest: the transposed scalar stores are conflict-free
+        const int idx = min((int)threadIdx.x + NT * it, TOT - 1), sl = idx & 31, d = (idx >> 5) * 4;
+        const int w = min(slot_word(sl), Nq - 1);
+        v[it] = ldg4(src + ((size_t)b * Nq + w) * dl + min(d, dl - 4));
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = (int)threadIdx.x + NT * it, sl = idx & 31, d = (idx >> 5) * 4;
+        if (idx < TOT) {
+            const float4 x = f4sel(slot_word(sl) < Nq && d < dl, v[it]);
+            sT[(d + 0) * LDW + sl] = x.x; sT[(d + 1) * LDW + sl] = x.y; sT[(d + 2) * LDW + sl] = x.z; sT[(d + 3) * LDW + sl] = x.w;
+        }
+    }
+}
+template <int DL, int NT>
+__device__ __forceinline__ void stage_vectors(float* sS, float* sU, float* sQ, const float* shat, const float* uq, const float* qmask, int b, int dl, int Nq)
+{
+    const int t = threadIdx.x;
+    for (int d = t; d < DL; d += NT) sS[d] = d < dl ? shat[(size_t)b * dl + d] : 0.f;
+    if (t < 32) {
+        const int w = slot_word(t);
+        sU[t] = w < Nq ? uq[(size_t)b * Nq + w] : 0.f;
+        sQ[t] = w < Nq ? qmask[(size_t)b * Nq + w] : 0.f;
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+// LDS (floats): sM [32][DL+4] | sWT [DL][36] | sS [DL] | sU [32] | sQ [32]
 template <int DL>
-__global__ __launch_bounds__(256, 3)
-void content_attn_fwd16_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
-                               const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
-                               const float* __restrict__ shat, const float* __restrict__ qmask,
-                               float* __restrict__ cchat, float* __restrict__ ccmean, int dl, int Nq, int cells_per_chunk, float scale)
+static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + DL * LDW + DL + 64); }
+
+template <int DL, int WS>
+__global__ __launch_bounds__(256, 2)
+void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
+                             const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
+                             const float* __restrict__ shat, const float* __restrict__ qmask,
+                             float* __restrict__ cchat, float* __restrict__ ccmean, int dl, int Nq, int N, int cells_per_range, float scale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
-    const int n_begin = s0 + chunk * cells_per_chunk;
-    if (n_begin >= s1) return;
-    const int n_end = min(s1, n_begin + cells_per_chunk);
+    constexpr int KJ = DL / 16;
+    float* sM = smem_dyn; float* sWT = sM + 32 * (DL + 4); float* sS = sWT + DL * LDW; float* sU = sS + DL; float* sQ = sU + 32;
+    const int n_lo = blockIdx.x * cells_per_range;
+    if (n_lo >= N) return;
+    const int n_hi = min(N, n_lo + cells_per_range);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kg = lane >> 4;
     const float invC = 1.0f / C;
-    AttnLds<DL> s(smem_dyn, false);
-    stage_sample<DL>(s, false, Mq, uq, what, shat, qmask, b, dl, Nq);
-    __syncthreads();
 
-    for (int n0 = n_begin + 4 * wave; n0 < n_end; n0 += 16) {
-        const RowGeom g = row_geom16(cells, n0, n_end, C, lane);
-        float ch[DL / 16][4], P[8], Ao[4];
-        load_rows16<DL>(ch, chat, g, dl, kg);
-        scores_softmax16<DL>(P, ch, s, Nq, scale, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        clip_attention16<DL>(Ao, ch, P, s, g, Nq, scale, lane);
-#pragma unroll
-        for (int j = 0; j < DL / 16; ++j) {                         // cchat = A chat
-            float o4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x = ch[j][q];
-                o4[q] = Ao[0] * x;
-                fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
-            }
-            const int d = 16 * j + 4 * kg;
-            if (cchat) {
-                if (g.ok && d < dl) stg4(cchat + (size_t)g.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
-            }
-            if (ccmean) {                                           // mean over the clips of the quad (padding lanes hold 0)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o4[q] = (o4[q] + nb<1>(o4[q]) + nb<2>(o4[q]) + nb<3>(o4[q])) * invC;
-                if (g.ok && (lane & 3) == 0 && d < dl)
-                    stg4(ccmean + (size_t)(g.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+    for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
+        const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
+        const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
+        __syncthreads();                                          // the previous segment's tiles are done with the LDS images
+        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq);
+        stage_feature_major<DL, 256>(sWT, what, b, dl, Nq);
+        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
+        __syncthreads();
 
-template <int DL>
-__global__ __launch_bounds__(256, 2)
-void content_attn_bwd16_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
-                               const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
-                               const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
-                               const float* __restrict__ shat, const float* __restrict__ qmask,
-                               float* __restrict__ dchat, float* __restrict__ da_out, float* __restrict__ ds_out, float* __restrict__ p_out,
-                               int dl, int Nq, int cells_per_chunk, float scale, int g_per_cell, float gscale,
-                               const float* __restrict__ dmean2, float mscale)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    constexpr int LDM = AttnLds<DL>::LDM, KJ = DL / 16;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
-    const int n_begin = s0 + chunk * cells_per_chunk;
-    if (n_begin >= s1) return;
-    const int n_end = min(s1, n_begin + cells_per_chunk);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kg = lane >> 4, l15 = lane & 15;
-    AttnLds<DL> s(smem_dyn, true);
-    stage_sample<DL>(s, true, Mq, uq, what, shat, qmask, b, dl, Nq);
-    __syncthreads();
-
-    for (int n0 = n_begin + 4 * wave; n0 < n_end; n0 += 16) {
-        const RowGeom g = row_geom16(cells, n0, n_end, C, lane);
-        float ch[KJ][4], P[8], Ao[4];
-        load_rows16<DL>(ch, chat, g, dl, kg);
-        float4 gq[KJ];                                              // gradient rows: requested now, consumed after the recompute
+        int n0 = n + 4 * wave;
+        RowGeom g = row_geom16(cells, n0, seg_end, C, lane);
+        float4 raw[KJ];
+        fetch_rows16<DL>(raw, chat, g.row, dl, kg);
+        for (; n0 < seg_end; n0 += 16) {
+            float ch[KJ][4], P[8], Ao[4];
+            mask_rows16<DL>(ch, raw, g.ok, dl, kg);
+            const RowGeom gc = g;
+            // the next tile's rows are requested before this tile's arithmetic (clamped when there is none)
+            g = row_geom16(cells, n0 + 16, seg_end, C, lane);
+            fetch_rows16<DL>(raw, chat, g.row, dl, kg);
+            scores_softmax16<DL, WS>(P, ch, sM, sU, sQ, Nq, scale, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            clip_attention16<DL>(Ao, ch, sS, gc, scale, lane, [&](int j) {
+                f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+                return words_tile16_T<WS>(z4, j, P, sWT, lane);
+            });
 #pragma unroll
-        for (int j = 0; j < KJ; ++j)
-            gq[j] = ldg4(dcchat + (size_t)(g_per_cell ? g.row / C : g.row) * dl + min(16 * j + 4 * kg, dl - 4));
-        float4 gm[KJ];                                              // second consumer's gradient (per cell), when there is one
-        if (dmean2) {
+            for (int j = 0; j < KJ; ++j) {                          // cchat = A chat
+                float o4[4];
 #pragma unroll
-            for (int j = 0; j < KJ; ++j) gm[j] = ldg4(dmean2 + (size_t)(g.row / C) * dl + min(16 * j + 4 * kg, dl - 4));
-        }
-        scores_softmax16<DL>(P, ch, s, Nq, scale, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        clip_attention16<DL>(Ao, ch, P, s, g, Nq, scale, lane);
-
-        // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
-        float dch[KJ][4];
-        float dAo[4] = {0.f, 0.f, 0.f, 0.f};
-        const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
+                for (int q = 0; q < 4; ++q) {
+                    const float x = ch[j][q];
+                    o4[q] = Ao[0] * x;
+                    fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
+                }
+                const int d = 16 * j + 4 * kg;
+                if (cchat) {
+                    if (gc.ok && d < dl) stg4(cchat + (size_t)gc.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                }
+                if (ccmean) {                                       // mean over the clips of the quad (padding lanes hold 0)
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const int d = 16 * j + 4 * kg;
-            const bool dok = g.ok && d < dl;
-            const float gs = dok ? gscale : 0.f;
-            float gv[4] = {gq[j].x * gs, gq[j].y * gs, gq[j].z * gs, gq[j].w * gs};
-            if (dmean2) {
-                const float ms = dok ? mscale : 0.f;
-                gv[0] = fmaf(gm[j].x, ms, gv[0]); gv[1] = fmaf(gm[j].y, ms, gv[1]); gv[2] = fmaf(gm[j].z, ms, gv[2]); gv[3] = fmaf(gm[j].w, ms, gv[3]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x = ch[j][q], y = gv[q];
-                dAo[0] = fmaf(y, x, dAo[0]);
-                fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
-                dch[j][q] = Ao[0] * y;
-                fmac_nb_sum(dch[j][q], y, An1, An2, An3);
-            }
-            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // A = softmax(Z) * m ; Z symmetric in (c, c')
-        float sym[4];
-        {
-            float rd = 0.f, dZ[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { dAo[o] = kg_sum(dAo[o]); rd = fmaf(Ao[o], dAo[o], rd); }
-#pragma unroll
-            for (int o = 0; o < 4; ++o) dZ[o] = g.nbok[o] ? Ao[o] * (dAo[o] - rd) : 0.f;
-            sym[0] = 2.0f * dZ[0] * scale;
-            sym[1] = (dZ[1] + nb<1>(dZ[1])) * scale;
-            sym[2] = (dZ[2] + nb<2>(dZ[2])) * scale;
-            sym[3] = (dZ[3] + nb<3>(dZ[3])) * scale;
-        }
-        // per 16-feature block: a (MFMA) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
-        //                       -> da to HBM and straight into  dP^T[w][n] += sum_d what[w][d] da^T[d][n]  (MFMA)
-        f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const f32x4v acc = attend_tile16<DL>(j, P, s, Nq, lane);
-            const float4 sh = ldg4(s.sS + 16 * j + 4 * kg);
-            const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
-            float da4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float tq = acc[q] + shv[q];
-                const float qv = ch[j][q] * tq;
-                float dq = sym[0] * qv;
-                fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
-                dch[j][q] = fmaf(dq, tq, dch[j][q]);
-                da4[q] = dq * ch[j][q];
-            }
-            const int d = 16 * j + 4 * kg;
-            if (g.ok && d < dl) stg4(da_out + (size_t)g.row * dl + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
-            const float4 w0 = ldg4(s.sW + l15 * LDM + d);
-            dP0 = mfma16(w0.x, da4[0], dP0); dP0 = mfma16(w0.y, da4[1], dP0); dP0 = mfma16(w0.z, da4[2], dP0); dP0 = mfma16(w0.w, da4[3], dP0);
-            if (Nq > 16) {
-                const float4 w1 = ldg4(s.sW + (16 + l15) * LDM + d);
-                dP1 = mfma16(w1.x, da4[0], dP1); dP1 = mfma16(w1.y, da4[1], dP1); dP1 = mfma16(w1.z, da4[2], dP1); dP1 = mfma16(w1.w, da4[3], dP1);
-            }
-            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // P = softmax(S), S = (raw + u) * scale * qmask
-        float pd = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pd = fmaf(P[r], (r < 4 ? dP0[r & 3] : dP1[r & 3]), pd);
-        pd = kg_sum(pd);
-        float dS[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            dS[r] = P[r] * ((r < 4 ? dP0[r & 3] : dP1[r & 3]) - pd) * s.sQ[16 * (r >> 2) + 4 * kg + (r & 3)] * scale;
-        if (g.ok) {
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
-                stg4(ds_out + (size_t)g.row * 32 + 16 * b2 + 4 * kg, make_float4(dS[4 * b2], dS[4 * b2 + 1], dS[4 * b2 + 2], dS[4 * b2 + 3]));
-                stg4(p_out + (size_t)g.row * 32 + 16 * b2 + 4 * kg, make_float4(P[4 * b2], P[4 * b2 + 1], P[4 * b2 + 2], P[4 * b2 + 3]));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // raw = chat Mq^T :  dchat^T[d][n] += sum_w Mq[w][d] dS^T[w][n]   -> dchat = (...) * m   (chat = linear(fc) * m)
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            f32x4v acc = {dch[j][0], dch[j][1], dch[j][2], dch[j][3]};
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
-                if (16 * b2 < Nq) {
-                    const float4 m4 = ldg4(s.sMT + (16 * j + l15) * LDW + 16 * b2 + 4 * kg);
-                    acc = mfma16(m4.x, dS[4 * b2], acc); acc = mfma16(m4.y, dS[4 * b2 + 1], acc);
-                    acc = mfma16(m4.z, dS[4 * b2 + 2], acc); acc = mfma16(m4.w, dS[4 * b2 + 3], acc);
+                    for (int q = 0; q < 4; ++q) {                 // quad total in two DPP steps
+                        const float t1 = o4[q] + nb<1>(o4[q]);
+                        o4[q] = (t1 + nb<2>(t1)) * invC;
+                    }
+                    if (gc.ok && (lane & 3) == 0 && d < dl)
+                        stg4(ccmean + (size_t)(gc.row / C) * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
                 }
             }
-            const int d = 16 * j + 4 * kg;
-            if (g.ok && d < dl) stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[0] * g.m, acc[1] * g.m, acc[2] * g.m, acc[3] * g.m));
-            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        n = seg_end;
     }
 }
 
-// ---- per-sample word-side reductions on MFMA (operands straight from HBM, coalesced) ---------------------------
-//   dMq[w][d]  = sum_rows dS[row][w] chat[row][d]      dwhat[w][d] = sum_rows P[row][w] da[row][d]
-//   dshat[d]   = sum_rows da[row][d]                   duq[w]      = sum_rows dS[row][w]
-// grid (SPLITS, B); each wave reduces a contiguous row range and writes one partial slab
-//   [dM 32 x dl | dW 32 x dl | dshat dl | du 32]; content_attn_reduce_kernel sums the slabs in fixed order.
+// ---- backward with the word-side reductions fused ---------------------------------------------------------------------
+// 512 threads = 8 waves, one workgroup per CU.  LDS (floats):
+//   sM [32][DL+4] | sW [32][DL+4] | sS [DL] | sU [32] | sQ [32] | tDa [128][DL+4] | tDs [128][36] | tP [128][36]
+// A round = 8 tiles (one per wave) = 32 cells = 128 rows:  tile phase (per wave, as the forward + gradients; dchat to HBM;
+// da, dS, P rows into the round tiles)  ->  barrier  ->  reduction phase: wave (kind, fq) accumulates the 32 x 32 block
+// [32 slots] x [features 32fq ..] of dMq = dS^T chat (kind 0; chat rows come back from L2) or dwhat = P^T da (kind 1) over
+// the 128 rows with 64 v_mfma_f32_32x32x2_f32, plus the column sums duq / dshat  ->  barrier.
+// Per (range, sample) segment the accumulators go to slab[range + sample]:  [dM 32 x dl | dW 32 x dl | dshat dl | du 32]
+// in slot order; content_attn_reduce_kernel sums a sample's slabs in range order (fixed order: deterministic).
 template <int DL>
-__global__ __launch_bounds__(256, 2)
-void content_attn_wordgrad_kernel(const float* __restrict__ chat, const float* __restrict__ da, const float* __restrict__ dS, const float* __restrict__ P,
-                                  const int* __restrict__ row_ptr, int L, int C, int dl, int splits, float* __restrict__ slab)
+static size_t bwd_lds_bytes() { return sizeof(float) * (size_t)(64 * (DL + 4) + DL + 64 + 128 * (DL + 4) + 256 * LDP); }
+
+template <int DL, int WS>
+__global__ __launch_bounds__(512, 2)
+void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
+                             const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
+                             const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
+                             const float* __restrict__ shat, const float* __restrict__ qmask,
+                             float* __restrict__ dchat, float* __restrict__ slab,
+                             int dl, int Nq, int N, int cells_per_range, float scale, int g_per_cell, float gscale,
+                             const float* __restrict__ dmean2, float mscale)
 {
-    constexpr int DT = (DL + 31) / 32;
-    const int b = blockIdx.y, sp = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-    const int r0 = row_ptr[b * L] * C, r1 = row_ptr[(b + 1) * L] * C;
-    const int parts = splits * 4, part = sp * 4 + wave;
-    const int per = ((r1 - r0 + parts - 1) / parts + 1) & ~1;            // even number of rows per wave
-    const int rb = r0 + part * per, re = min(r1, rb + per);
-    f32x16 aM[DT], aW[DT];
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    constexpr int LDM = DL + 4, KJ = DL / 16, LDA = DL + 4, DT = (DL + 31) / 32;
+    float* sM = smem_dyn; float* sW = sM + 32 * LDM; float* sS = sW + 32 * LDM; float* sU = sS + DL; float* sQ = sU + 32;
+    float* tDa = sQ + 32; float* tDs = tDa + 128 * LDA; float* tP = tDs + 128 * LDP;
+    const int rg = blockIdx.x;
+    const int n_lo = rg * cells_per_range;
+    if (n_lo >= N) return;
+    const int n_hi = min(N, n_lo + cells_per_range);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kg = lane >> 4, l15 = lane & 15;
+    const int kind = wave >> 2, fq = wave & 3, l31 = lane & 31, h = lane >> 5;
+    const size_t slab_sz = (size_t)64 * dl + dl + 32;
+
+    for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
+        const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
+        const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
+        __syncthreads();
+        stage_slot_major<DL, 512>(sM, Mq, b, dl, Nq);
+        stage_slot_major<DL, 512>(sW, what, b, dl, Nq);
+        stage_vectors<DL, 512>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
+        __syncthreads();
+        f32x16 racc;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+        float csum = 0.f;
+
+        // the rows of a round (chat, output gradients) are requested one round ahead, before the previous round's reduction
+        // phase, so that their HBM latency hides behind it
+        float4 raw[KJ], gq[KJ], gm[KJ];
+        RowGeom g = row_geom16(cells, n + 4 * wave, seg_end, C, lane);
+        fetch_rows16<DL>(raw, chat, g.row, dl, kg);
+        fetch_rows16<DL>(gq, dcchat, g_per_cell ? g.row / C : g.row, dl, kg);
+        if (dmean2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+
+        for (int c0 = n; c0 < seg_end; c0 += 32) {                // rounds
+            {
+                float ch[KJ][4], P[8], Ao[4];
+                float gv[KJ][4];                                    // effective output-gradient rows (both consumers summed, masked)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { aM[dt][r] = 0.f; aW[dt][r] = 0.f; }
-    float sh[DT], du = 0.f;
+                for (int j = 0; j < KJ; ++j) {
+                    const bool dok = g.ok && 16 * j + 4 * kg < dl;
+                    const float gs = dok ? gscale : 0.f, ms = dok ? mscale : 0.f;
+                    gv[j][0] = gq[j].x * gs; gv[j][1] = gq[j].y * gs; gv[j][2] = gq[j].z * gs; gv[j][3] = gq[j].w * gs;
+                    if (dmean2) {
+                        gv[j][0] = fmaf(gm[j].x, ms, gv[j][0]); gv[j][1] = fmaf(gm[j].y, ms, gv[j][1]);
+                        gv[j][2] = fmaf(gm[j].z, ms, gv[j][2]); gv[j][3] = fmaf(gm[j].w, ms, gv[j][3]);
+                    }
+                }
+                mask_rows16<DL>(ch, raw, g.ok, dl, kg);
+                __builtin_amdgcn_sched_barrier(0);                  // the prefetched registers die here
+                scores_softmax16<DL, WS>(P, ch, sM, sU, sQ, Nq, scale, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                clip_attention16<DL>(Ao, ch, sS, g, scale, lane, [&](int j) {
+                    f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+                    return words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
+                });
+
+                // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
+                float dch[KJ][4];
+                float dAo[4] = {0.f, 0.f, 0.f, 0.f};
+                const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) sh[dt] = 0.f;
-    // two row pairs per iteration: all loads of an iteration are issued before the first MFMA consumes them
-    for (int row2 = rb; row2 < re; row2 += 4) {                  // wave-uniform trip count: MFMA needs every lane live
-        float gs[2], ps[2], cv[2][DT], dv[2][DT];
+                for (int j = 0; j < KJ; ++j) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const bool ok = row2 + 2 * u + h < re;
-            const size_t row = (size_t)min(row2 + 2 * u + h, re - 1);
-            gs[u] = ok ? dS[row * 32 + l31] : 0.f;
-            ps[u] = ok ? P[row * 32 + l31] : 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = ch[j][q], y = gv[j][q];
+                        dAo[0] = fmaf(y, x, dAo[0]);
+                        fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
+                        dch[j][q] = Ao[0] * y;
+                        fmac_nb_sum(dch[j][q], y, An1, An2, An3);
+                    }
+                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // A = softmax(Z) * m ; Z symmetric in (c, c')
+                float sym[4];
+                {
+                    float rd = 0.f, dZ[4];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = min(32 * dt + l31, dl - 1);
-                const bool dok = ok && 32 * dt + l31 < dl;
-                cv[u][dt] = dok ? chat[row * dl + d] : 0.f;
-                dv[u][dt] = dok ? da[row * dl + d] : 0.f;
+                    for (int o = 0; o < 4; ++o) { dAo[o] = kg_sum(dAo[o]); rd = fmaf(Ao[o], dAo[o], rd); }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) dZ[o] = g.nbok[o] ? Ao[o] * (dAo[o] - rd) : 0.f;
+                    sym[0] = 2.0f * dZ[0] * scale;
+                    sym[1] = (dZ[1] + nb<1>(dZ[1])) * scale;
+                    sym[2] = (dZ[2] + nb<2>(dZ[2])) * scale;
+                    sym[3] = (dZ[3] + nb<3>(dZ[3])) * scale;
+                }
+                // per 16-feature block: a (MFMA) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
+                //                       -> da into the round tile and straight into  dP^T[slot][n] += sum_d what[slot][d] da^T[d][n]  (MFMA)
+                f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f};
+                float* myDa = tDa + (16 * wave + l15) * LDA;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4v acc = words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
+                    const float4 sh = ldg4(sS + 16 * j + 4 * kg);
+                    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    float da4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float tq = acc[q] + shv[q];
+                        const float qv = ch[j][q] * tq;
+                        float dq = sym[0] * qv;
+                        fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
+                        dch[j][q] = fmaf(dq, tq, dch[j][q]);
+                        da4[q] = dq * ch[j][q];                     // 0 on padding lanes and past dl (ch is 0 there)
+                    }
+                    const int d = 16 * j + 4 * kg;
+                    stg4(myDa + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
+                    const float4 w0 = ldg4(sW + l15 * LDM + d);
+                    dP0 = mfma16(w0.x, da4[0], dP0); dP0 = mfma16(w0.y, da4[1], dP0); dP0 = mfma16(w0.z, da4[2], dP0); dP0 = mfma16(w0.w, da4[3], dP0);
+                    if (WS > 4) {
+                        const float4 w1 = ldg4(sW + (16 + l15) * LDM + d);
+                        dP1 = mfma16(w1.x, da4[0], dP1); dP1 = mfma16(w1.y, da4[1], dP1); dP1 = mfma16(w1.z, da4[2], dP1); dP1 = mfma16(w1.w, da4[3], dP1);
+                    }
+                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                // P = softmax(S), S = (raw + u) * scale * qmask
+                float pd = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) pd = fmaf(P[r], (r < 4 ? dP0[r & 3] : dP1[r & 3]), pd);
+                pd = kg_sum(pd);
+                float dS[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    dS[r] = g.ok ? P[r] * ((r < 4 ? dP0[r & 3] : dP1[r & 3]) - pd) * sQ[16 * (r >> 2) + 4 * kg + (r & 3)] * scale : 0.f;
+                {
+                    float* myDs = tDs + (16 * wave + l15) * LDP;
+                    float* myP = tP + (16 * wave + l15) * LDP;
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        stg4(myDs + 16 * b2 + 4 * kg, make_float4(dS[4 * b2], dS[4 * b2 + 1], dS[4 * b2 + 2], dS[4 * b2 + 3]));
+                        stg4(myP + 16 * b2 + 4 * kg, g.ok ? make_float4(P[4 * b2], P[4 * b2 + 1], P[4 * b2 + 2], P[4 * b2 + 3]) : f4zero());
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // raw = chat Mq^T :  dchat^T[d][n] += sum_slots Mq[slot][d] dS^T[slot][n]   -> dchat = (...) * m   (chat = linear(fc) * m)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    f32x4v acc = {dch[j][0], dch[j][1], dch[j][2], dch[j][3]};
+                    acc = words_tile16_S<LDM, WS>(acc, j, dS, sM, lane);
+                    const int d = 16 * j + 4 * kg;
+                    if (g.ok && d < dl) stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[0] * g.m, acc[1] * g.m, acc[2] * g.m, acc[3] * g.m));
+                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // next round's rows (past the segment: clamped to its last row, never used)
+            g = row_geom16(cells, c0 + 32 + 4 * wave, seg_end, C, lane);
+            fetch_rows16<DL>(raw, chat, g.row, dl, kg);
+            fetch_rows16<DL>(gq, dcchat, g_per_cell ? g.row / C : g.row, dl, kg);
+            if (dmean2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+            __syncthreads();                                        // the round's da / dS / P rows are in LDS
+            if (fq < DT) {
+                const int feat = 32 * fq + l31;
+                const bool fok = feat < dl;
+                const float* At = (kind ? tP : tDs) + h * LDP + l31;
+                if (kind) {
+                    const float* Bt = tDa + h * LDA + min(feat, DL - 1);
+#pragma unroll 8
+                    for (int s2 = 0; s2 < 64; ++s2) {
+                        const float bv = Bt[2 * s2 * LDA];
+                        racc = mfma32(At[2 * s2 * LDP], bv, racc);
+                        csum += bv;                                 // dshat[feat]
+                    }
+                } else {
+                    // chat rows of the round back from L2 (this workgroup has just read them), 16 rows in flight
+                    const float* cbase = chat + min(feat, dl - 1);
+#pragma unroll
+                    for (int s0 = 0; s0 < 64; s0 += 8) {
+                        float bv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int t = 2 * (s0 + u) + h, cell = c0 + (t >> 2), c = t & 3;
+                            const bool ok = cell < seg_end && c < C;
+                            const size_t row = ok ? (size_t)cell * C + c : (size_t)c0 * C;
+                            const float x = cbase[row * dl];
+                            bv[u] = (ok && fok) ? x : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float av = At[2 * (s0 + u) * LDP];
+                            racc = mfma32(av, bv[u], racc);
+                            csum += av;                             // duq[slot]
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                        // tiles may be overwritten by the next round
+        }
+        // the segment's partial result
+        float* sl = slab + (size_t)(rg + b) * slab_sz;
+        if (fq < DT) {
+            const int feat = 32 * fq + l31;
+            if (feat < dl) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sl[(size_t)(kind * 32 + wmap(r, h)) * dl + feat] = racc[r];
+            }
+            const float cs = csum + __shfl_xor(csum, 32);
+            if (h == 0) {
+                if (kind) { if (feat < dl) sl[(size_t)64 * dl + feat] = cs; }
+                else if (fq == 0) sl[(size_t)64 * dl + dl + l31] = cs;
             }
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            du += gs[u];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                sh[dt] += dv[u][dt];
-                aM[dt] = mfma32(gs[u], cv[u][dt], aM[dt]);
-                aW[dt] = mfma32(ps[u], dv[u][dt], aW[dt]);
-            }
-        }
+        n = seg_end;
     }
-    const size_t slab_sz = (size_t)2 * 32 * dl + dl + 32;
-    float* sl = slab + ((size_t)b * parts + part) * slab_sz;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int w = wmap(r, h), d = 32 * dt + l31;
-            if (d < dl) { sl[(size_t)w * dl + d] = aM[dt][r]; sl[(size_t)(32 + w) * dl + d] = aW[dt][r]; }
-        }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const float v = sh[dt] + __shfl_xor(sh[dt], 32);
-        const int d = 32 * dt + l31;
-        if (h == 0 && d < dl) sl[(size_t)64 * dl + d] = v;
-    }
-    du += __shfl_xor(du, 32);
-    if (h == 0) sl[(size_t)64 * dl + dl + l31] = du;
 }
 
-__global__ void content_attn_reduce_kernel(const float* __restrict__ slab, int dl, int Nq, int parts,
+// dMq / dwhat / dshat / duq of sample b = sum of its segments' slabs, in range order
+__global__ void content_attn_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ row_ptr, int L, int dl, int Nq, int cells_per_range,
                                            float* __restrict__ dMq, float* __restrict__ dwhat, float* __restrict__ dshat, float* __restrict__ duq)
 {
     const int b = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int slab_sz = 2 * 32 * dl + dl + 32;
     if (x >= slab_sz) return;
-    const float* p = slab + (size_t)b * parts * slab_sz + x;
+    const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
     float s = 0.f;
-    for (int k = 0; k < parts; ++k) s += p[(size_t)k * slab_sz];
-    if (x < 32 * dl) { const int w = x / dl, d = x % dl; if (w < Nq) dMq[((size_t)b * Nq + w) * dl + d] = s; }
-    else if (x < 64 * dl) { const int y = x - 32 * dl, w = y / dl, d = y % dl; if (w < Nq) dwhat[((size_t)b * Nq + w) * dl + d] = s; }
+    if (s1 > s0) {
+        const int g_lo = s0 / cells_per_range, g_hi = (s1 - 1) / cells_per_range;
+        for (int g = g_lo; g <= g_hi; ++g) s += slab[(size_t)(g + b) * slab_sz + x];
+    }
+    if (x < 32 * dl) { const int w = slot_word(x / dl), d = x % dl; if (w < Nq) dMq[((size_t)b * Nq + w) * dl + d] = s; }
+    else if (x < 64 * dl) { const int y = x - 32 * dl, w = slot_word(y / dl), d = y % dl; if (w < Nq) dwhat[((size_t)b * Nq + w) * dl + d] = s; }
     else if (x < 64 * dl + dl) dshat[(size_t)b * dl + (x - 64 * dl)] = s;
-    else { const int w = x - 64 * dl - dl; if (w < Nq) duq[(size_t)b * Nq + w] = s; }
+    else { const int w = slot_word(x - 64 * dl - dl); if (w < Nq) duq[(size_t)b * Nq + w] = s; }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
-template <int DL>
-static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
+static int attn_num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// equal ranges of the cell list, one per workgroup slot; whole tiles (4 cells), at least `min_cells`
+static int range_cells(int N, int slots, int min_cells)
+{
+    int c = cdiv(cdiv(N, slots), 4) * 4;
+    return c < min_cells ? min_cells : c;
+}
+int content_attn_bwd_range_cells(int N) { return range_cells(N, attn_num_cus(), 32); }
+
+template <int DL, int WS>
+static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* cc_rows, float* cc_mean, int dl, int Nq)
 {
-    int cpc, mc; chunking(L, &cpc, &mc);
-    hipLaunchKernelGGL((content_attn_fwd16_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(false), st, chat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, cpc, 1.0f / sqrtf((float)dl));
+    (void)B;
+    const int cpr = range_cells(N, 2 * attn_num_cus(), 16);      // two 256-thread workgroups per CU (203 registers)
+    hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS>), dim3(cdiv(N, cpr)), dim3(256), fwd_lds_bytes<DL>(), st, chat, cells, row_ptr, L, C,
+                       Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl));
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int B, int L, int C,
+// kernels exist for these (feature width, word steps) pairs: the production width 128 with 4 / 5 / 6 / 8 steps of four
+// words (Nq <= 16 / 20 / 24 / 32), narrower widths with 4 or 8
+#define SMIN_ATTN_DISPATCH(FN, ...)                                                                        \
+    do {                                                                                                    \
+        const int nws__ = (Nq + 3) / 4;                                                                      \
+        if (dl <= 16) return nws__ <= 4 ? FN<16, 4>(__VA_ARGS__) : FN<16, 8>(__VA_ARGS__);                     \
+        if (dl <= 32) return nws__ <= 4 ? FN<32, 4>(__VA_ARGS__) : FN<32, 8>(__VA_ARGS__);                     \
+        if (dl <= 64) return nws__ <= 4 ? FN<64, 4>(__VA_ARGS__) : FN<64, 8>(__VA_ARGS__);                     \
+        if (nws__ <= 4) return FN<128, 4>(__VA_ARGS__);                                                        \
+        if (nws__ == 5) return FN<128, 5>(__VA_ARGS__);                                                        \
+        if (nws__ == 6) return FN<128, 6>(__VA_ARGS__);                                                        \
+        return FN<128, 8>(__VA_ARGS__);                                                                     \
+    } while (0)
+
+int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                             float* cc_rows, float* cc_mean, int dl, int Nq)
 {
-    if (dl <= 16) return fwd_t<16>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
-    if (dl <= 32) return fwd_t<32>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
-    if (dl <= 64) return fwd_t<64>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
-    return fwd_t<128>(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
+    if (N <= 0) return 0;
+    SMIN_ATTN_DISPATCH(fwd_t, st, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
 }
 
-size_t content_attn_bwd_ws_floats(int M, int B, int dl)
+// slabs: one per (range, sample) segment, indexed range + sample
+size_t content_attn_bwd_ws_floats(int N, int B, int dl)
 {
-    return (size_t)M * dl + 2 * (size_t)M * 32 + (size_t)B * ATTN_SPLITS * 4 * ((size_t)64 * dl + dl + 32) + 64;
+    const int cpr = content_attn_bwd_range_cells(N > 0 ? N : 1);
+    return ((size_t)cdiv(N > 0 ? N : 1, cpr) + B + 1) * ((size_t)64 * dl + dl + 32) + 64;
 }
 
-template <int DL>
-static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
+template <int DL, int WS>
+static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
                  const float* dmean2, float mscale)
 {
-    int cpc, mc; chunking(L, &cpc, &mc);
-    float* da = ws;
-    float* dS = da + (size_t)M * dl;
-    float* P = dS + (size_t)M * 32;
-    float* slab = P + (size_t)M * 32;
-    hipLaunchKernelGGL((content_attn_bwd16_kernel<DL>), dim3(mc, B), dim3(256), AttnLds<DL>::bytes(true), st, chat, dcchat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, dchat, da, dS, P, dl, Nq, cpc, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
-    SMIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((content_attn_wordgrad_kernel<DL>), dim3(ATTN_SPLITS, B), dim3(256), 0, st, chat, da, dS, P, row_ptr, L, C, dl, ATTN_SPLITS, slab);
+    const int cpr = content_attn_bwd_range_cells(N);
+    static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bwd_lds_bytes<DL>());
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS>), dim3(cdiv(N, cpr)), dim3(512), bwd_lds_bytes<DL>(), st, chat, dcchat, cells, row_ptr, L, C,
+                       Mq, uq, what, shat, qmask, dchat, ws, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
     SMIN_LAUNCH_CHECK();
     const int slab_sz = 64 * dl + dl + 32;
-    hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, slab, dl, Nq, ATTN_SPLITS * 4, dMq, dwhat, dshat, duq);
+    hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, ws, row_ptr, L, dl, Nq, cpr, dMq, dwhat, dshat, duq);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int M, int B, int L, int C,
+int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                             const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                             float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
                             const float* dmean2, float mscale)
 {
-    if (dl <= 16) return bwd_t<16>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
-    if (dl <= 32) return bwd_t<32>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
-    if (dl <= 64) return bwd_t<64>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
-    return bwd_t<128>(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
+    SMIN_ATTN_DISPATCH(bwd_t, st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, g_per_cell, gscale, dmean2, mscale);
 }
 
 }  // namespace smin
@@ -573,12 +717,13 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
     if (N == 0) return 0;
     SMIN_REQUIRE(cc || ccmean);
     ProfScope prof((hipStream_t)stream, SMIN_PROF_ATTN_FWD);
-    return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
+    return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
 }
 
 extern "C" size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl)
 {
-    return sizeof(float) * (content_attn_bwd_ws_floats(N * C, B, dl) + 64);
+    (void)C;
+    return sizeof(float) * (content_attn_bwd_ws_floats(N, B, dl) + 64);
 }
 
 // Gradients dcc [N*C][dl] and/or dccmean [N][dl] (either may be NULL, not both) -> dchat and the per-sample word-side
@@ -593,12 +738,11 @@ extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float
     if (N == 0) return 0;
     SMIN_REQUIRE(dcc || dccmean);
     SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));
-    const int M = N * C;
     float* aws = reinterpret_cast<float*>(ws);
     const float* g = dcc; const float* g2 = nullptr; int per_cell = 0; float gscale = 1.0f;
     if (dcc && dccmean) g2 = dccmean;                               // both consumers: summed while the rows are loaded
     else if (!dcc) { g = dccmean; per_cell = 1; gscale = 1.0f / C; }
     ProfScope prof(st, SMIN_PROF_ATTN_BWD);
-    return launch_content_attn_bwd(st, chat, g, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq,
+    return launch_content_attn_bwd(st, chat, g, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq,
                                    per_cell, gscale, g2, 1.0f / C);
 }

@@ -153,7 +153,7 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
     const int M = N * C;
     int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, C}, M, dl, D);
     if (rc) return rc;
-    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, B, L, C, Mq, uq, what, shat, qmask, last ? nullptr : cchat, last ? cchat : nullptr, dl, Nq);
+    rc = launch_content_attn_fwd(st, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, last ? nullptr : cchat, last ? cchat : nullptr, dl, Nq);
     if (rc) return rc;
     if (last)                       // cchat holds mean_c cchat [N][dl]; a quarter of the rows, and fc_out is never written
         return launch_gemm_nt(st, PlainMat{cchat, dl}, PlainMat{Wc, dl}, EpLastMean{bc, cells, fcmean_in, hbar, fcmean}, N, D, dl);
@@ -188,7 +188,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     const int sp1 = tn_splits(last ? N : M, D, dl), sp2 = tn_splits(M, dl, D);
     float* slab1 = take((size_t)sp1 * D * dl); float* bslab1 = take((size_t)sp1 * D);
     float* slab2 = take((size_t)sp2 * dl * D); float* bslab2 = take((size_t)sp2 * dl);
-    float* aws = take(content_attn_bwd_ws_floats(M, B, dl));
+    float* aws = take(content_attn_bwd_ws_floats(N, B, dl));
     SMIN_REQUIRE(off * sizeof(float) <= ws_bytes);
     const DoutEffMat<true, HAS_DFC> dout{dfc_out, dfcmean, cells, C, D, invC};
 
@@ -210,7 +210,7 @@ static int content_unit_bwd_impl(hipStream_t st, const float* dfc_out, const flo
     }
     rc = launch_reduce_slabs2(st, slab1, dWc, D * dl, bslab1, dbc, D, sp1); if (rc) return rc;
     // (c) attention core backward -> dchat (already multiplied by m: masked cells write 0)
-    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, M, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f, nullptr, 0.f);
+    rc = launch_content_attn_bwd(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, aws, dl, Nq, last, 1.0f, nullptr, 0.f);
     if (rc) return rc;
     // (d) dfc = dchat @ Wch + dout (residual)     [M, D], contraction over dl;  dhbar = sum_c dout (gate term)
     if (C == 4) {
