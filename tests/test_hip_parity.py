@@ -244,6 +244,37 @@ def test_batch_targets_on_device(dev):
                     assert torch.equal(a.to(v.dtype).reshape(v.shape), v), (T, L, b, k)
 
 
+def test_native_host_equals_python_host(dev):
+    """The torch-extension host (csrc/torch_binding.cpp, the default) and the Python host (functional.py / modules.py) drive the
+    same kernels in the same order: scores and every parameter gradient must agree bit for bit."""
+    from oracle import smin_oracle as O
+    import vml_amd.training as TR
+    from vml_amd import loss_fn
+    import models
+    for (T, L, C, D, dl, layers, Din, Nq, Hh, B) in [(64, 16, 4, 128, 32, 3, 40, 9, 64, 5), (128, 64, 4, 512, 128, 3, 500, 20, 256, 3)]:
+        sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+        batch = O.synthetic_batch(B, T, L, Nq, Din, seed=21)
+        b = {k: v.to(dev) for k, v in batch.items()}
+        res = []
+        for native in (True, False):
+            m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+            m.native_host = native
+            TR.NATIVE_LOSS = native
+            try:
+                out = m(*H.model_inputs(b))
+                loss = loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"])
+                loss.backward()
+            finally:
+                TR.NATIVE_LOSS = True
+            res.append(([o.detach().clone() for o in out], loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+        (o1, l1, g1), (o2, l2, g2) = res
+        assert torch.equal(l1, l2)
+        for x, y in zip(o1, o2):
+            assert torch.equal(x, y)
+        for k in g1:
+            assert torch.equal(g1[k], g2[k]), k
+
+
 # ---------------------------------------------------------------- size-independent properties at BASELINE size
 def test_properties_full_size(dev):
     from oracle import smin_oracle as O

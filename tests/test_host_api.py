@@ -82,6 +82,26 @@ def test_library_exports_every_declared_symbol():
     assert loaded.smin_workspace_bytes(1000, 2, 4, 512, 128, 20) > 0
 
 
+def test_torch_extension_registers_operators():
+    """csrc/torch_binding.cpp: TORCH_LIBRARY(smin_hip) loads without a GPU, exposes the two operators with the documented
+    schemas, and refuses CPU tensors (no CPU fallback behind the extension either)."""
+    import models
+    ops = models.vml_amd._lib.load_torch()
+    assert ops.abi_version() == 1
+    schema = str(torch.ops.smin_hip.smin_forward.default._schema)
+    for name in ("video_features", "video_mask", "query_features", "query_mask", "length_mask", "moment_mask", "Tensor[] params", "int[] cfg"):
+        assert name in schema, schema
+    m = models.SMIN(16, 8, 4, 32, 16, 2, 24, 5, 16)
+    ps = m._native_params()
+    assert len(ps) == len(list(m.parameters())) == 19 + 20 * 2 + 8
+    assert {id(p) for p in ps} == {id(p) for p in m.parameters()}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.smin_forward(torch.zeros(2, 16, 24), torch.ones(2, 16, 1, dtype=torch.uint8), torch.zeros(2, 5, 300), torch.ones(2, 5, 1, dtype=torch.uint8),
+                         torch.ones(2, 8, dtype=torch.bool), torch.ones(2, 8, 8, dtype=torch.bool), ps, [16, 8, 4, 32, 16, 2, 5, 16, 1, 1])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.smin_loss(*[torch.zeros(2, 8, 8)] * 4, *[torch.zeros(2, 8)] * 9)
+
+
 def test_product_path_fails_loudly_on_cpu():
     import models
     from oracle import smin_oracle as O

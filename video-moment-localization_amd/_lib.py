@@ -8,6 +8,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmin_hip.so")
+TORCH_LIB_PATH = os.path.join(_HERE, "libsmin_torch.so")        # TORCH_LIBRARY(smin_hip, ...): csrc/torch_binding.cpp
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -100,6 +101,28 @@ def load():
         raise SminHipError("libsmin_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+_torch_ops = None
+
+
+def load_torch():
+    """The torch-extension binding (csrc/torch_binding.cpp): registers torch.ops.smin_hip.{smin_forward, smin_loss} -- the
+    whole forward as one library call with its autograd graph built in C++.  Raises if the library is missing."""
+    global _torch_ops
+    if _torch_ops is not None:
+        return _torch_ops
+    load()                                            # the C ABI library it links against
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise SminHipError(
+            f"{TORCH_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or set SMIN.native_host = False to drive the same kernels from the Python host)")
+    torch.ops.load_library(TORCH_LIB_PATH)
+    ops = torch.ops.smin_hip
+    if ops.abi_version() != 1:
+        raise SminHipError("libsmin_torch.so / libsmin_hip.so ABI version mismatch")
+    _torch_ops = ops
+    return ops
 
 
 def ptr(t):

@@ -466,14 +466,21 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
 template <class AM, class BM_, bool BIAS>
 __global__ __launch_bounds__(256, 3)
 void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__ bias_slab,
-                    int Mrows, int I, int J, int rows_per_split)
+                    int Mrows, int I, int J, int rows_per_split, int tiles_i, int tiles_j, int splits)
 {
     constexpr int BI = 128, BJ = 128, BK = 16, NP = BK / 8;          // 32 KB of LDS -> 3 workgroups per CU
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BI + BJ)];
     float* As = smem;
     float* Bs = smem + 2 * BK * BI;
 
-    const int ti = blockIdx.x, tj = blockIdx.y, z = blockIdx.z;
+    // XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch) and its L2.  All output tiles of one row
+    // split read the same A / B rows, so a split's tiles are consecutive slots of ONE XCD: the rows are fetched from HBM
+    // once per split instead of once per XCD that happens to hold one of its tiles (3.0x the algorithmic bytes before).
+    const int tiles = tiles_i * tiles_j;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int z = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (z >= splits) return;
+    const int ti = tile % tiles_i, tj = tile / tiles_i;
     const int m_begin = z * rows_per_split;
     const int m_end = min(Mrows, m_begin + rows_per_split);
     const int t = threadIdx.x, lk = t >> 5, c4 = (t & 31) * 4;
@@ -594,11 +601,14 @@ static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, fl
                                  int Mrows, int I, int J, int splits)
 {
     const int rows_per_split = cdiv(cdiv(Mrows, splits), 32) * 32;
-    dim3 grid(cdiv(I, 128), cdiv(J, 128), splits);
+    const int tiles_i = cdiv(I, 128), tiles_j = cdiv(J, 128);
+    dim3 grid(cdiv(splits, 8) * 8 * tiles_i * tiles_j);
     if (bias_slab)
-        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split);
+        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+                           tiles_i, tiles_j, splits);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split);
+        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+                           tiles_i, tiles_j, splits);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

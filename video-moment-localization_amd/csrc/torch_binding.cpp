@@ -1,0 +1,726 @@
+// Torch extension binding of the SMIN hot path: TORCH_LIBRARY(smin_hip, ...) over the C ABI of include/smin_hip.h.
+//
+// The reference's operator boundary is the nn.Module surface of models.py; below it the drop-in runs as
+// ONE library call per forward: smin_hip::smin_forward takes the six forward arguments of SMIN.forward
+// (reference models.py:367) plus the module's parameters and builds the whole autograd graph in C++ --
+// torch::autograd::Function nodes around the HIP entry points, one per reference module body, so the backward pass runs
+// on the autograd engine's thread without the interpreter (DistributedDataParallel hooks fire as usual).
+// The Python host (video-moment-localization_amd/functional.py, modules.py) binds the same C ABI with ctypes; it
+// serves the stand-alone sub-module seams and remains as a second host for the in-model path (SMIN.native_host = False),
+// kernel for kernel the same launches.  torch types appear only in this file; libsmin_hip.so knows pointers and sizes.
+//
+// Only the in-model fast path lives here: the content stream on a mask-driven cell list.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "smin_hip.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using HStream = c10::hip::HIPStream;
+
+#define SMIN_CK(call)                                                                           \
+    do {                                                                                        \
+        const int rc__ = (call);                                                                \
+        TORCH_CHECK(rc__ == 0, "smin_hip: " #call " failed with code ", rc__,                   \
+                    rc__ < -1000 ? " (argument rejected at csrc line " + std::to_string(-rc__ - 1000) + ")" : std::string()); \
+    } while (0)
+
+// ---------------------------------------------------------------- small helpers
+inline const float* fp(const Tensor& t) { return t.defined() ? t.const_data_ptr<float>() : nullptr; }
+inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline const int32_t* ip(const Tensor& t) { return t.const_data_ptr<int32_t>(); }
+inline void* cur() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+inline Tensor cont(const Tensor& t) { return t.defined() ? t.contiguous() : t; }
+inline Tensor fl(const Tensor& t) { return t.scalar_type() == at::kFloat ? t : t.to(at::kFloat); }
+inline int i32(int64_t v) { return static_cast<int>(v); }
+
+struct StreamScope {                       // torch's current stream for the scope (what torch.cuda.stream(s) does)
+    HStream prev;
+    explicit StreamScope(HStream s) : prev(c10::hip::getCurrentHIPStream(s.device_index())) { c10::hip::setCurrentHIPStream(s); }
+    ~StreamScope() { c10::hip::setCurrentHIPStream(prev); }
+};
+
+hipEvent_t next_event()
+{
+    static std::mutex mu;
+    static std::vector<hipEvent_t> ring;
+    static size_t pos = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ring.empty()) {
+        ring.resize(256);
+        for (auto& e : ring) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    }
+    return ring[pos++ % ring.size()];
+}
+// `waiter` waits for everything queued on `on` so far (stream.wait_stream)
+void wait_stream(HStream waiter, HStream on)
+{
+    if (waiter == on) return;
+    hipEvent_t e = next_event();
+    TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed");
+    TORCH_CHECK(hipStreamWaitEvent(waiter.stream(), e, 0) == hipSuccess, "hipStreamWaitEvent failed");
+}
+void record_stream(const Tensor& t, HStream s)
+{
+    if (t.defined() && t.has_storage()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), s);
+}
+HStream side_stream(c10::DeviceIndex dev)
+{
+    static std::mutex mu;
+    static std::map<int, HStream> streams;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(dev);
+    if (it == streams.end()) it = streams.emplace((int)dev, c10::hip::getStreamFromPool(false, dev)).first;
+    return it->second;
+}
+
+// persistent scratch per (device, stream): calls on one stream are stream-ordered, two streams never share scratch
+struct Scratch { void* p; size_t n; Tensor hold; };
+Scratch scratch(size_t nbytes, const at::Device& dev)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int64_t>, Tensor> bufs;
+    const auto st = c10::hip::getCurrentHIPStream(dev.index());
+    std::lock_guard<std::mutex> lk(mu);
+    Tensor& b = bufs[{(int)dev.index(), (int64_t)st.id()}];
+    if (!b.defined() || (size_t)b.numel() < nbytes)
+        b = at::empty({(int64_t)(nbytes + nbytes / 4 + 4096)}, at::TensorOptions().dtype(at::kByte).device(dev));
+    return Scratch{b.data_ptr(), (size_t)b.numel(), b};
+}
+
+struct Layout {                           // packed valid-cell layout, mask-driven: every listed cell has m = 1
+    Tensor cells, row_ptr, cellmap;
+    int N = 0, B = 0, L = 0;
+};
+
+// the geometry's clip-boundary table, built once per (device, T, L, C)
+std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, int C)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, std::pair<Tensor, Tensor>> tabs;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_tuple((int)dev.index(), T, L, C);
+    auto it = tabs.find(key);
+    if (it != tabs.end()) return it->second;
+    auto io = at::TensorOptions().dtype(at::kInt).device(dev);
+    Tensor counts = at::empty({T}, io);
+    SMIN_CK(smin_clip_event_table(cur(), T, L, C, counts.data_ptr<int32_t>(), nullptr, nullptr));
+    Tensor offsets = at::zeros({T + 1}, io);
+    offsets.slice(0, 1).copy_(at::cumsum(counts, 0).to(at::kInt));
+    const int64_t n = std::max<int64_t>(1, offsets[T].item<int64_t>());
+    Tensor table = at::empty({n, 2}, io);
+    SMIN_CK(smin_clip_event_table(cur(), T, L, C, nullptr, ip(offsets), table.data_ptr()));
+    return tabs.emplace(key, std::make_pair(offsets, table)).first->second;
+}
+
+Tensor undef() { return Tensor(); }
+
+// ---------------------------------------------------------------- autograd nodes (one per reference module body)
+
+// f = ((x W^T + b + pe[t]) * vmask) * f_s   -- VideoEncoder.forward + Backbone's Hadamard product (models.py:25-36, 81-83)
+struct VideoFuse : torch::autograd::Function<VideoFuse> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor W, Tensor bias, Tensor pe, Tensor vmask, Tensor fs)
+    {
+        x = cont(x); W = cont(W); bias = cont(bias); pe = cont(pe); vmask = cont(vmask); fs = cont(fs);
+        const int B = i32(x.size(0)), T = i32(x.size(1)), Din = i32(x.size(2)), D = i32(W.size(0));
+        Tensor fv = at::empty({B, T, D}, x.options()), f = at::empty({B, T, D}, x.options());
+        SMIN_CK(smin_video_encoder_fwd(cur(), fp(x), fp(W), fp(bias), fp(pe), fp(vmask), fp(fs), B, T, Din, D, fpm(fv), fpm(f)));
+        ctx->save_for_backward({x, fv, fs, vmask});
+        ctx->saved_data["pe_rows"] = pe.size(0);
+        return f;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &x = sv[0], &fv = sv[1], &fs = sv[2], &vmask = sv[3];
+        const int B = i32(x.size(0)), T = i32(x.size(1)), Din = i32(x.size(2)), D = i32(fv.size(2));
+        const int64_t pe_rows = ctx->saved_data["pe_rows"].toInt();
+        Tensor df = cont(g[0]);
+        Tensor dW = at::empty({D, Din}, x.options()), dbias = at::empty({D}, x.options());
+        Tensor dpe = pe_rows != T ? at::zeros({pe_rows, D}, x.options()) : at::empty({T, D}, x.options());
+        Tensor dfs = at::empty_like(fs);
+        auto ws = scratch(smin_video_encoder_bwd_workspace_bytes(B, T, Din, D), x.device());
+        SMIN_CK(smin_video_encoder_bwd(cur(), fp(df), fp(fv), fp(fs), fp(vmask), fp(x), B, T, Din, D, fpm(dW), fpm(dbias), fpm(dpe), fpm(dfs),
+                                       ws.p, ws.n));
+        return {undef(), dW, dbias, dpe, undef(), dfs};
+    }
+};
+
+// one bidirectional LSTM layer over a padded batch with per-sample lengths (models.py:46-58)
+struct BiLstmLayer : torch::autograd::Function<BiLstmLayer> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor length, Tensor w_ih_f, Tensor w_hh_f, Tensor b_ih_f, Tensor b_hh_f,
+                          Tensor w_ih_r, Tensor w_hh_r, Tensor b_ih_r, Tensor b_hh_r)
+    {
+        x = cont(x);
+        const int B = i32(x.size(0)), Nq = i32(x.size(1)), In = i32(x.size(2)), H = i32(w_hh_f.size(1));
+        Tensor Wih = at::cat({w_ih_f, w_ih_r}).contiguous();                           // [8H, In]
+        Tensor bias = at::cat({b_ih_f + b_hh_f, b_ih_r + b_hh_r}).contiguous();        // [8H]
+        Tensor Whh = at::stack({w_hh_f, w_hh_r}).contiguous();                         // [2, 4H, H]
+        Tensor W4 = Whh.view({2, 4, H, H}).permute({0, 3, 2, 1}).contiguous();         // [2, k, u, gate]
+        Tensor G = at::empty({B, Nq, 2, 4 * H}, x.options()), Hout = at::empty({B, Nq, 2 * H}, x.options()), Cs = at::empty({B, Nq, 2, H}, x.options());
+        SMIN_CK(smin_bilstm_layer_fwd(cur(), fp(x), fp(Wih), fp(bias), fp(W4), ip(length), B, Nq, In, H, fpm(G), fpm(Hout), fpm(Cs)));
+        ctx->save_for_backward({x, Hout, G, Cs, Wih, Whh});
+        ctx->saved_data["len"] = length;
+        return Hout;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &x = sv[0], &Hout = sv[1], &G = sv[2], &Cs = sv[3], &Wih = sv[4], &Whh = sv[5];
+        const Tensor length = ctx->saved_data["len"].toTensor();
+        const int B = i32(x.size(0)), Nq = i32(x.size(1)), In = i32(x.size(2)), H = i32(Whh.size(2));
+        Tensor dH = cont(g[0]);
+        Tensor dX = ctx->needs_input_grad(0) ? at::empty_like(x) : Tensor();
+        Tensor dWih = at::empty_like(Wih), dbias = at::empty({8 * H}, x.options()), dWhh = at::empty_like(Whh);
+        auto ws = scratch(smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, H), x.device());
+        Tensor WihT = Wih.t().contiguous();
+        SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(x), fp(Hout), fp(G), fp(Cs), fp(WihT), fp(Whh), ip(length), B, Nq, In, H,
+                                      fpm(dX), fpm(dWih), fpm(dbias), fpm(dWhh), ws.p, ws.n));
+        const int64_t H4 = 4 * H;
+        Tensor db_f = dbias.slice(0, 0, H4), db_r = dbias.slice(0, H4);
+        return {dX, undef(), dWih.slice(0, 0, H4), dWhh[0], db_f, db_f, dWih.slice(0, H4), dWhh[1], db_r, db_r};
+    }
+};
+
+// ProposalGeneration.forward without f_c: (f_m, f_b) (models.py:115-126; the content stream never forms f_c)
+struct ProposalMeans : torch::autograd::Function<ProposalMeans> {
+    static variable_list forward(AutogradContext* ctx, Tensor f, Tensor cells, Tensor row_ptr, Tensor cellmap, int64_t N, int64_t T, int64_t L, int64_t C)
+    {
+        f = cont(f);
+        const int B = i32(f.size(0)), D = i32(f.size(2));
+        TORCH_CHECK(f.size(1) == T, "ProposalGeneration was built for T=", T, " but got ", f.size(1), " frames");
+        Tensor fm = at::empty({N, D}, f.options()), fb = at::empty({B, L, D}, f.options());
+        auto ws = scratch((size_t)8 * B * (T + 1) * D, f.device());
+        SMIN_CK(smin_proposal_map_fwd(cur(), fp(f), ip(cells), i32(N), B, i32(T), i32(L), i32(C), D, nullptr, fpm(fm), fpm(fb), ws.p, ws.n));
+        ctx->saved_data["cells"] = cells; ctx->saved_data["row_ptr"] = row_ptr; ctx->saved_data["cellmap"] = cellmap;
+        ctx->saved_data["d"] = std::vector<int64_t>{N, B, T, L, C, D};
+        return {fm, fb};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto d = ctx->saved_data["d"].toIntVector();
+        const int N = i32(d[0]), B = i32(d[1]), T = i32(d[2]), L = i32(d[3]), C = i32(d[4]), D = i32(d[5]);
+        const Tensor cells = ctx->saved_data["cells"].toTensor(), row_ptr = ctx->saved_data["row_ptr"].toTensor(), cellmap = ctx->saved_data["cellmap"].toTensor();
+        Tensor dfm = cont(g[0]), dfb = cont(g[1]);
+        const Tensor& ref = dfm.defined() ? dfm : dfb;
+        Tensor df = at::empty({B, T, D}, ref.options());
+        auto ws = scratch((size_t)4 * B * T * D, df.device());
+        auto tab = clip_event_table(df.device(), T, L, C);
+        SMIN_CK(smin_proposal_map_bwd(cur(), nullptr, fp(dfm), fp(dfb), ip(cells), ip(row_ptr), ip(cellmap), N, B, T, L, C, D, fpm(df), ws.p, ws.n,
+                                      ip(tab.first), tab.second.data_ptr()));
+        return {df, undef(), undef(), undef(), undef(), undef(), undef(), undef()};
+    }
+};
+
+// out[s][n, c] = mean over clip c of cell n of g[b, t, s*W:(s+1)*W] + bias[s*W ..]  (models.py:117, 247 through g = f [Wch_1; ..]^T)
+struct ClipWindowMeans : torch::autograd::Function<ClipWindowMeans> {
+    static variable_list forward(AutogradContext* ctx, Tensor g, Tensor bias, Tensor cells, Tensor row_ptr, Tensor cellmap, int64_t N, int64_t T,
+                                 int64_t L, int64_t C, int64_t nseg)
+    {
+        g = cont(g); bias = cont(bias);
+        const int B = i32(g.size(0)), D = i32(g.size(2)), W = D / i32(nseg);
+        Tensor out = at::empty({nseg, N * C, W}, g.options());
+        auto ws = scratch((size_t)8 * B * (T + 1) * D, g.device());
+        const int nb = bias.defined() ? i32(bias.numel()) : 0;
+        SMIN_CK(smin_clip_window_means_fwd(cur(), fp(g), fp(bias), nb, ip(cells), i32(N), B, i32(T), i32(L), i32(C), W, i32(nseg), fpm(out), ws.p, ws.n));
+        ctx->saved_data["cells"] = cells; ctx->saved_data["row_ptr"] = row_ptr; ctx->saved_data["cellmap"] = cellmap;
+        ctx->saved_data["d"] = std::vector<int64_t>{N, B, T, L, C, W, nseg, nb};
+        variable_list outs;
+        for (int64_t s = 0; s < nseg; ++s) outs.push_back(out[s]);
+        return outs;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto d = ctx->saved_data["d"].toIntVector();
+        const int N = i32(d[0]), B = i32(d[1]), T = i32(d[2]), L = i32(d[3]), C = i32(d[4]), W = i32(d[5]), nseg = i32(d[6]), nb = i32(d[7]);
+        const Tensor cells = ctx->saved_data["cells"].toTensor(), row_ptr = ctx->saved_data["row_ptr"].toTensor(), cellmap = ctx->saved_data["cellmap"].toTensor();
+        at::TensorOptions opt;
+        for (auto& t : g) if (t.defined()) { opt = t.options(); break; }
+        std::vector<Tensor> douts(nseg);
+        std::vector<const float*> ptrs(nseg);
+        for (int s = 0; s < nseg; ++s) {
+            douts[s] = g[s].defined() ? cont(g[s]) : at::zeros({(int64_t)N * C, W}, opt);
+            ptrs[s] = fp(douts[s]);
+        }
+        Tensor dg = at::empty({B, T, (int64_t)W * nseg}, opt);
+        auto ws = scratch((size_t)4 * B * T * W * nseg, dg.device());
+        auto tab = clip_event_table(dg.device(), T, L, C);
+        SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), N, B, T, L, C, W, nseg, fpm(dg), ws.p, ws.n,
+                                           ip(tab.first), tab.second.data_ptr()));
+        Tensor dbias;
+        if (ctx->needs_input_grad(1) && nb) {
+            std::vector<Tensor> parts;
+            for (int s = 0; s < nb / W; ++s) parts.push_back(douts[s].sum(0));
+            dbias = at::cat(parts);
+        }
+        return {dg, dbias, undef(), undef(), undef(), undef(), undef(), undef(), undef(), undef()};
+    }
+};
+
+// the content unit's attention core (models.py:252-267): chat [N*C, dl] -> (cc [N*C, dl], ccmean [N, dl])
+struct ContentAttn : torch::autograd::Function<ContentAttn> {
+    static variable_list forward(AutogradContext* ctx, Tensor chat, Tensor Mq, Tensor uq, Tensor what, Tensor shat, Tensor qmask, Tensor cells, Tensor row_ptr,
+                                 int64_t N, int64_t L, int64_t C, bool want_rows)
+    {
+        chat = cont(chat); Mq = cont(Mq); uq = cont(uq); what = cont(what); shat = cont(shat); qmask = cont(qmask);
+        const int B = i32(what.size(0)), Nq = i32(what.size(1)), dl = i32(what.size(2));
+        Tensor cc = at::empty({want_rows ? N * C : 0, dl}, chat.options()), ccmean = at::empty({N, dl}, chat.options());
+        SMIN_CK(smin_content_attn_fwd(cur(), fp(chat), ip(cells), ip(row_ptr), i32(N), B, i32(L), i32(C), dl, Nq, fp(Mq), fp(uq), fp(what), fp(shat), fp(qmask),
+                                      want_rows ? fpm(cc) : nullptr, fpm(ccmean)));
+        ctx->save_for_backward({chat, Mq, uq, what, shat, qmask});
+        ctx->saved_data["cells"] = cells; ctx->saved_data["row_ptr"] = row_ptr;
+        ctx->saved_data["d"] = std::vector<int64_t>{N, L, C, want_rows};
+        if (!want_rows) ctx->mark_non_differentiable({cc});
+        return {cc, ccmean};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &chat = sv[0], &Mq = sv[1], &uq = sv[2], &what = sv[3], &shat = sv[4], &qmask = sv[5];
+        auto d = ctx->saved_data["d"].toIntVector();
+        const int N = i32(d[0]), L = i32(d[1]), C = i32(d[2]);
+        const bool want_rows = d[3] != 0;
+        const Tensor cells = ctx->saved_data["cells"].toTensor(), row_ptr = ctx->saved_data["row_ptr"].toTensor();
+        const int B = i32(what.size(0)), Nq = i32(what.size(1)), dl = i32(what.size(2));
+        Tensor dcc = want_rows ? cont(g[0]) : Tensor(), dccmean = cont(g[1]);
+        if (!dcc.defined() && !dccmean.defined()) dccmean = at::zeros({N, dl}, chat.options());
+        Tensor dchat = at::empty_like(chat), dMq = at::empty_like(Mq), duq = at::empty_like(uq), dwhat = at::empty_like(what), dshat = at::empty_like(shat);
+        if (N == 0) { dMq.zero_(); duq.zero_(); dwhat.zero_(); dshat.zero_(); }
+        else {
+            auto ws = scratch(smin_content_attn_bwd_workspace_bytes(N, B, C, dl), chat.device());
+            SMIN_CK(smin_content_attn_bwd(cur(), fp(dcc), fp(dccmean), fp(chat), ip(cells), ip(row_ptr), N, B, L, C, dl, Nq, fp(Mq), fp(uq), fp(what), fp(shat),
+                                          fp(qmask), fpm(dchat), fpm(dMq), fpm(duq), fpm(dwhat), fpm(dshat), ws.p, ws.n));
+        }
+        return {dchat, dMq, duq, dwhat, dshat, undef(), undef(), undef(), undef(), undef(), undef(), undef()};
+    }
+};
+
+// y[r] = [x_0[r] | x_1[r] | ..] W^T + bias + add_rows[r] + add_cells[r / C]
+struct LinearRows : torch::autograd::Function<LinearRows> {
+    // (optional inputs are std::optional: an undefined Tensor is not a legal autograd input)
+    static Tensor forward(AutogradContext* ctx, Tensor W, std::optional<Tensor> bias_, std::optional<Tensor> add_rows_, std::optional<Tensor> add_cells_, int64_t C,
+                          at::TensorList xs_in)          // (a std::vector<Tensor> argument would be taken for a non-tensor)
+    {
+        std::vector<Tensor> xs(xs_in.begin(), xs_in.end());
+        W = cont(W);
+        Tensor bias = bias_ ? cont(*bias_) : Tensor(), add_rows = add_rows_ ? cont(*add_rows_) : Tensor(), add_cells = add_cells_ ? cont(*add_cells_) : Tensor();
+        for (auto& x : xs) x = cont(x);
+        const int R = i32(xs[0].size(0)), K = i32(xs[0].size(1)), O = i32(W.size(0)), nseg = i32(xs.size());
+        Tensor y = at::empty({R, O}, xs[0].options());
+        std::vector<const float*> ptrs;
+        for (auto& x : xs) ptrs.push_back(fp(x));
+        SMIN_CK(smin_linear_rows_fwd(cur(), ptrs.data(), nseg, fp(W), fp(bias), fp(add_rows), fp(add_cells), i32(C), R, O, K, fpm(y)));
+        variable_list save{W};
+        for (auto& x : xs) save.push_back(x);
+        ctx->save_for_backward(save);
+        // AutogradContext::needs_input_grad counts graph edges, i.e. only the tensor inputs that are present
+        int64_t e = 1;
+        const int64_t e_bias = bias_ ? e++ : -1, e_rows = add_rows_ ? e++ : -1, e_cells = add_cells_ ? e++ : -1;
+        ctx->saved_data["d"] = std::vector<int64_t>{C, e_bias, e_rows, e_cells, e};
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor& W = sv[0];
+        const int nseg = i32(sv.size()) - 1;
+        auto dd = ctx->saved_data["d"].toIntVector();
+        const int64_t C = dd[0], e_bias = dd[1], e_rows = dd[2], e_cells = dd[3], e_x = dd[4];
+        auto need = [&](int64_t e) { return e >= 0 && ctx->needs_input_grad((size_t)e); };
+        Tensor dy = cont(g[0]);
+        const int R = i32(sv[1].size(0)), K = i32(sv[1].size(1)), O = i32(W.size(0));
+        bool want_dx = false;
+        for (int s = 0; s < nseg; ++s) want_dx = want_dx || need(e_x + s);
+        std::vector<Tensor> dxs;
+        std::vector<const float*> xp;
+        std::vector<float*> dxp;
+        for (int s = 0; s < nseg; ++s) {
+            xp.push_back(fp(sv[1 + s]));
+            if (want_dx) { dxs.push_back(at::empty_like(sv[1 + s])); dxp.push_back(fpm(dxs.back())); }
+        }
+        Tensor dW = at::empty_like(W);
+        Tensor dbias = need(e_bias) ? at::empty({O}, dy.options()) : Tensor();
+        auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(R, O, nseg * K), dy.device());
+        Tensor WT = W.t().contiguous();
+        SMIN_CK(smin_linear_rows_bwd(cur(), fp(dy), xp.data(), nseg, fp(WT), R, O, K, want_dx ? dxp.data() : nullptr, fpm(dW), fpm(dbias), ws.p, ws.n));
+        Tensor dcells;
+        if (need(e_cells)) {
+            if (C == 1) dcells = dy;
+            else {
+                dcells = at::empty({R / C, O}, dy.options());
+                SMIN_CK(smin_group_sum(cur(), fp(dy), i32(R / C), i32(C), O, fpm(dcells)));
+            }
+        }
+        variable_list out{dW, dbias, need(e_rows) ? dy : Tensor(), dcells, undef()};
+        for (int s = 0; s < nseg; ++s) out.push_back(want_dx ? dxs[s] : Tensor());
+        return out;
+    }
+};
+
+// hbar = sigmoid(fm * fs) * fm (models.py:191, 272-274), n_hbar views of it followed by n_res views of fm: every
+// consumer gets its own view so that the one backward kernel sums their gradients
+struct Gate : torch::autograd::Function<Gate> {
+    static variable_list forward(AutogradContext* ctx, Tensor fm, Tensor fs, Tensor cells, Tensor row_ptr, int64_t B, int64_t L, int64_t n_hbar, int64_t n_res)
+    {
+        fm = cont(fm); fs = cont(fs);
+        const int N = i32(fm.size(0)), D = i32(fm.size(1));
+        Tensor hbar = at::empty_like(fm);
+        SMIN_CK(smin_gate_fwd(cur(), fp(fm), fp(fs), ip(cells), N, D, fpm(hbar)));
+        ctx->save_for_backward({fm, fs});
+        ctx->saved_data["row_ptr"] = row_ptr;
+        ctx->saved_data["d"] = std::vector<int64_t>{B, L, n_hbar};
+        variable_list outs{hbar};
+        for (int64_t k = 1; k < n_hbar; ++k) outs.push_back(at::alias(hbar));
+        for (int64_t k = 0; k < n_res; ++k) outs.push_back(at::alias(fm));
+        return outs;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &fm = sv[0], &fs = sv[1];
+        auto d = ctx->saved_data["d"].toIntVector();
+        const int B = i32(d[0]), L = i32(d[1]), n_hbar = i32(d[2]);
+        const Tensor row_ptr = ctx->saved_data["row_ptr"].toTensor();
+        const int N = i32(fm.size(0)), D = i32(fm.size(1));
+        std::vector<Tensor> keep;
+        std::vector<const float*> dh, dr;
+        for (int k = 0; k < (int)g.size(); ++k) {
+            if (!g[k].defined()) continue;
+            keep.push_back(cont(g[k]));
+            (k < n_hbar ? dh : dr).push_back(fp(keep.back()));
+        }
+        if (dh.empty()) { keep.push_back(at::zeros_like(fm)); dh.push_back(fp(keep.back())); }
+        Tensor dfm = at::empty_like(fm), dfs = at::empty_like(fs);
+        auto ws = scratch((size_t)4 * B * 512 * D + 4096, fm.device());
+        SMIN_CK(smin_gate_bwd(cur(), dh.data(), i32(dh.size()), dr.empty() ? nullptr : dr.data(), i32(dr.size()), fp(fm), fp(fs), ip(row_ptr), N, B, L, D,
+                              fpm(dfm), fpm(dfs), ws.p, ws.n));
+        return {dfm, dfs, undef(), undef(), undef(), undef(), undef(), undef()};
+    }
+};
+
+// BoundaryUnit.forward with its word attention (models.py:137-196)
+struct BoundaryUnitFn : torch::autograd::Function<BoundaryUnitFn> {
+    static Tensor forward(AutogradContext* ctx, Tensor fb, Tensor fw, Tensor fs, Tensor hbar, Tensor Wq, Tensor bq, Tensor Wk, Tensor bk, Tensor qmask, Tensor lmask,
+                          Tensor cells, Tensor row_ptr, int64_t N)
+    {
+        fb = cont(fb); fw = cont(fw); fs = cont(fs); hbar = cont(hbar); Wq = cont(Wq); bq = cont(bq); Wk = cont(Wk); bk = cont(bk); qmask = cont(qmask); lmask = cont(lmask);
+        const int B = i32(fb.size(0)), L = i32(fb.size(1)), D = i32(fb.size(2)), Nq = i32(fw.size(1));
+        Tensor out = at::empty_like(fb), Qb = at::empty_like(fb), baq = at::empty_like(fb), bqv = at::empty_like(fb), Kb = at::empty_like(fw);
+        Tensor P = at::empty({B, L, Nq}, fb.options()), A = at::empty({B, L, L}, fb.options());
+        SMIN_CK(smin_boundary_unit_fwd(cur(), fp(fb), fp(fw), fp(fs), fp(hbar), ip(cells), ip(row_ptr), i32(N), B, L, Nq, D, fp(Wq), fp(bq), fp(Wk), fp(bk),
+                                       fp(qmask), fp(lmask), fpm(out), fpm(Qb), fpm(Kb), fpm(P), fpm(baq), fpm(bqv), fpm(A)));
+        ctx->save_for_backward({fb, fw, fs, hbar, Wq, Wk, qmask, lmask, Qb, Kb, P, baq, bqv, A});
+        ctx->saved_data["cells"] = cells; ctx->saved_data["row_ptr"] = row_ptr; ctx->saved_data["N"] = N;
+        return out;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &fb = sv[0], &fw = sv[1], &fs = sv[2], &hbar = sv[3], &Wq = sv[4], &Wk = sv[5], &qmask = sv[6], &lmask = sv[7], &Qb = sv[8], &Kb = sv[9],
+                     &P = sv[10], &baq = sv[11], &bqv = sv[12], &A = sv[13];
+        const Tensor cells = ctx->saved_data["cells"].toTensor(), row_ptr = ctx->saved_data["row_ptr"].toTensor();
+        const int N = i32(ctx->saved_data["N"].toInt());
+        const int B = i32(fb.size(0)), L = i32(fb.size(1)), D = i32(fb.size(2)), Nq = i32(fw.size(1));
+        Tensor dout = cont(g[0]);
+        Tensor WqT = Wq.t().contiguous(), WkT = Wk.t().contiguous();
+        Tensor dfb = at::empty_like(fb), dfw = at::empty_like(fw), dfs = at::empty_like(fs), dhbar = at::empty_like(hbar);
+        Tensor dWq = at::empty_like(Wq), dbq = at::empty({D}, fb.options()), dWk = at::empty_like(Wk), dbk = at::empty({D}, fb.options());
+        const size_t nbytes = 4 * ((size_t)2 * B * L * L + (size_t)3 * B * L * D + (size_t)B * L * Nq + (size_t)B * Nq * D + (size_t)2 * 64 * ((size_t)D * D + D)) + 4096;
+        auto ws = scratch(nbytes, fb.device());
+        SMIN_CK(smin_boundary_unit_bwd(cur(), fp(dout), fp(fb), fp(fw), fp(fs), fp(hbar), ip(cells), ip(row_ptr), N, B, L, Nq, D, fp(WqT), fp(WkT), fp(qmask), fp(lmask),
+                                       fp(Qb), fp(Kb), fp(P), fp(baq), fp(bqv), fp(A), fpm(dfb), fpm(dfw), fpm(dfs), fpm(dhbar), fpm(dWq), fpm(dbq), fpm(dWk), fpm(dbk),
+                                       ws.p, ws.n));
+        return {dfb, dfw, dfs, dhbar, dWq, dbq, dWk, dbk, undef(), undef(), undef(), undef(), undef()};
+    }
+};
+
+// MomentUnit.forward (models.py:288-303); Wcat = [conv_fb.W | conv_fc.W] (D, 2D).  Returns (mu, view of fcmean)
+struct MomentUnitFn : torch::autograd::Function<MomentUnitFn> {
+    static variable_list forward(AutogradContext* ctx, Tensor fcmean, Tensor fm, Tensor fb, Tensor Wcat, Tensor bcat, Tensor cells, Tensor row_ptr, Tensor cellmap)
+    {
+        fcmean = cont(fcmean); fm = cont(fm); fb = cont(fb); Wcat = cont(Wcat); bcat = cont(bcat);
+        const int N = i32(fm.size(0)), D = i32(fm.size(1)), B = i32(fb.size(0)), L = i32(fb.size(1));
+        Tensor mu = at::empty_like(fm), x1 = at::empty_like(fm);           // x1 = f_b[i] * f_b[j], kept for the weight gradient
+        SMIN_CK(smin_pair_product(cur(), fp(fb), ip(cells), N, L, D, fpm(x1)));
+        SMIN_CK(smin_moment_unit_fwd(cur(), fp(fcmean), fp(fm), fp(fb), ip(cells), N, B, L, D, fp(Wcat), fp(bcat), fpm(mu), fp(x1)));
+        ctx->save_for_backward({fcmean, fb, Wcat, x1});
+        ctx->saved_data["cells"] = cells; ctx->saved_data["row_ptr"] = row_ptr; ctx->saved_data["cellmap"] = cellmap;
+        return {mu, at::alias(fcmean)};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &fcmean = sv[0], &fb = sv[1], &Wcat = sv[2], &x1 = sv[3];
+        const Tensor cells = ctx->saved_data["cells"].toTensor(), row_ptr = ctx->saved_data["row_ptr"].toTensor(), cellmap = ctx->saved_data["cellmap"].toTensor();
+        const int N = i32(fcmean.size(0)), D = i32(fcmean.size(1)), B = i32(fb.size(0)), L = i32(fb.size(1));
+        Tensor dmu = cont(g[0]), dacc = cont(g[1]);
+        if (!dmu.defined()) dmu = at::zeros_like(fcmean);
+        Tensor WcatT = Wcat.t().contiguous();
+        Tensor dfcmean = at::empty_like(fcmean), dfb = at::empty_like(fb), dWcat = at::empty_like(Wcat), dbcat = at::empty({D}, fb.options());
+        auto ws = scratch(smin_workspace_bytes(N, B, 4, D, 4, 1), fb.device());
+        SMIN_CK(smin_moment_unit_bwd(cur(), fp(dmu), fp(fcmean), fp(fb), ip(cells), ip(row_ptr), ip(cellmap), N, B, L, D, fp(WcatT), fpm(dfcmean), fpm(dfb), fpm(dWcat),
+                                     fpm(dbcat), ws.p, ws.n, 1, fp(dacc), fp(x1)));
+        return {dfcmean, dmu, dfb, dWcat, dbcat, undef(), undef(), undef()};
+    }
+};
+
+// Localization.forward (models.py:335-344): pm (B, L, L) dense, psea (3, B, L)
+struct ScoreMap : torch::autograd::Function<ScoreMap> {
+    static variable_list forward(AutogradContext* ctx, Tensor fm, Tensor fb, Tensor wm, Tensor bm, Tensor wb, Tensor bb, Tensor lmask, Tensor cells)
+    {
+        fm = cont(fm); fb = cont(fb); wm = cont(wm); bm = cont(bm); wb = cont(wb); bb = cont(bb); lmask = cont(lmask);
+        const int N = i32(fm.size(0)), D = i32(fm.size(1)), B = i32(fb.size(0)), L = i32(fb.size(1));
+        Tensor pm = at::empty({B, L, L}, fm.options()), psea = at::empty({3, B, L}, fm.options());
+        SMIN_CK(smin_score_map_fwd(cur(), fp(fm), fp(fb), ip(cells), N, B, L, D, fp(wm), fp(bm), fp(wb), fp(bb), fp(lmask), fpm(pm), fpm(psea)));
+        ctx->save_for_backward({fm, fb, wm, wb, lmask, pm, psea});
+        ctx->saved_data["cells"] = cells;
+        return {pm, psea};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &fm = sv[0], &fb = sv[1], &wm = sv[2], &wb = sv[3], &lmask = sv[4], &pm = sv[5], &psea = sv[6];
+        const Tensor cells = ctx->saved_data["cells"].toTensor();
+        const int N = i32(fm.size(0)), D = i32(fm.size(1)), B = i32(fb.size(0)), L = i32(fb.size(1));
+        Tensor dpm = g[0].defined() ? cont(g[0]) : at::zeros_like(pm), dpsea = g[1].defined() ? cont(g[1]) : at::zeros_like(psea);
+        Tensor dfm = at::empty_like(fm), dfb = at::empty_like(fb), dwm = at::empty_like(wm), dbm = at::empty({1}, fm.options()), dwb = at::empty_like(wb),
+               dbb = at::empty({3}, fm.options());
+        auto ws = scratch(smin_workspace_bytes(N, B, 4, D, 4, 1), fm.device());
+        SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), fp(dpsea), fp(pm), fp(psea), fp(fm), fp(fb), ip(cells), N, B, L, D, fp(wm), fp(wb), fp(lmask), fpm(dfm), fpm(dfb),
+                                   fpm(dwm), fpm(dbm), fpm(dwb), fpm(dbb), ws.p, ws.n));
+        return {dfm, dfb, dwm, dbm, dwb, dbb, undef(), undef()};
+    }
+};
+
+// restated loss of the reference's train loop (main.py:89-116): one forward and one backward kernel
+struct LossNode : torch::autograd::Function<LossNode> {
+    static Tensor forward(AutogradContext* ctx, Tensor pm, Tensor ps, Tensor pe, Tensor pa, Tensor ym, Tensor sm, Tensor mm, Tensor ys, Tensor ss, Tensor ye, Tensor se,
+                          Tensor ya, Tensor lm)
+    {
+        auto f = [](const Tensor& t) { return cont(fl(t)); };
+        auto b = [](const Tensor& t) { return cont((t.scalar_type() == at::kBool || t.scalar_type() == at::kByte) ? t : t.ne(0)); };
+        pm = f(pm); ps = f(ps); pe = f(pe); pa = f(pa); sm = f(sm); ss = f(ss); se = f(se);
+        ym = b(ym); mm = b(mm); ys = b(ys); ye = b(ye); ya = b(ya); lm = b(lm);
+        const int B = i32(ps.size(0)), L = i32(ps.size(1));
+        Tensor loss = at::empty({1}, pm.options()), part = at::empty({B, 6}, pm.options());
+        auto u8 = [](const Tensor& t) { return static_cast<const uint8_t*>(t.const_data_ptr()); };
+        SMIN_CK(smin_loss_fwd(cur(), fp(pm), u8(ym), fp(sm), u8(mm), fp(ps), u8(ys), fp(ss), fp(pe), u8(ye), fp(se), fp(pa), u8(ya), u8(lm), B, L, fpm(loss), fpm(part)));
+        ctx->save_for_backward({pm, ps, pe, pa, ym, sm, mm, ys, ss, ye, se, ya, lm, part});
+        return loss.reshape({});
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &pm = sv[0], &ps = sv[1], &pe = sv[2], &pa = sv[3], &ym = sv[4], &sm = sv[5], &mm = sv[6], &ys = sv[7], &ss = sv[8], &ye = sv[9], &se = sv[10],
+                     &ya = sv[11], &lm = sv[12], &part = sv[13];
+        const int B = i32(ps.size(0)), L = i32(ps.size(1));
+        Tensor dloss = cont(fl(g[0].reshape({1})));
+        Tensor dpm = at::empty_like(pm), dps = at::empty_like(ps), dpe = at::empty_like(pe), dpa = at::empty_like(pa);
+        auto u8 = [](const Tensor& t) { return static_cast<const uint8_t*>(t.const_data_ptr()); };
+        SMIN_CK(smin_loss_bwd(cur(), fp(dloss), fp(part), fp(pm), u8(ym), fp(sm), u8(mm), fp(ps), u8(ys), fp(ss), fp(pe), u8(ye), fp(se), fp(pa), u8(ya), u8(lm), B, L,
+                              fpm(dpm), fpm(dps), fpm(dpe), fpm(dpa)));
+        variable_list out{dpm, dps, dpe, dpa};
+        for (int k = 0; k < 9; ++k) out.push_back(undef());
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- the model
+
+// parameter order (modules.py: SMIN._native_params): video encoder 3, LSTM 16, 20 per SMI layer, localization 8
+enum { P_VE_W = 0, P_VE_B, P_PE, P_LSTM = 3, P_LAYER0 = 19 };
+enum { L_CH_W = 0, L_CH_B, L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_C_W, L_C_B, L_AQ_W, L_AQ_B, L_AK_W, L_AK_B, L_BQ_W, L_BQ_B, L_BK_W, L_BK_B, L_FB_W, L_FB_B, L_FC_W,
+       L_FC_B, L_COUNT };
+
+struct Words { Tensor Mq, uq, what, shat; };
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_features, const Tensor& video_mask, const Tensor& query_features, const Tensor& query_mask,
+                                                        const Tensor& length_mask, const Tensor& moment_mask, at::TensorList prm, at::IntArrayRef cfg)
+{
+    TORCH_CHECK(video_features.is_cuda(), "smin_forward runs on a HIP device only (there is no CPU fallback)");
+    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep]");
+    const int64_t T = cfg[0], L = cfg[1], C = cfg[2], D = cfg[3], nl = cfg[5], maxq = cfg[6], H = cfg[7];
+    const bool overlap_boundary = cfg[8] != 0, overlap_prep = cfg[9] != 0;
+    TORCH_CHECK((int64_t)prm.size() == P_LAYER0 + nl * L_COUNT + 8, "smin_forward: expected ", P_LAYER0 + nl * L_COUNT + 8, " parameters, got ", prm.size());
+    const at::Device dev = video_features.device();
+    c10::hip::HIPGuard device_guard(dev.index());
+    const int64_t B = video_features.size(0), Tn = video_features.size(1), Nq = query_features.size(1);
+    auto lp = [&](int64_t k, int which) -> const Tensor& { return prm[P_LAYER0 + k * L_COUNT + which]; };
+    const Tensor* loc = &prm[P_LAYER0 + nl * L_COUNT];
+
+    // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
+    Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
+    Tensor host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+    hipEvent_t count_ready = next_event();
+    TORCH_CHECK(hipEventRecord(count_ready, c10::hip::getCurrentHIPStream().stream()) == hipSuccess, "hipEventRecord failed");
+
+    // ---- backbone (models.py:38-83): BiLSTM x 2, heads, fused video encoder
+    Tensor qm = query_mask.reshape({B, -1});
+    Tensor length = qm.sum(1);
+    Tensor len32 = length.to(at::kInt);
+    Tensor x = query_features;
+    for (int layer = 0; layer < 2; ++layer) {
+        const Tensor* w = &prm[P_LSTM + 8 * layer];
+        x = BiLstmLayer::apply(x, len32, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+    }
+    Tensor fw = x;
+    if (Nq < maxq) fw = at::constant_pad_nd(fw, {0, 0, 0, maxq - Nq}, 0);
+    fw = fw.contiguous();
+    Tensor last = (length.to(at::kLong) - 1).clamp_min(0).view({B, 1, 1}).expand({B, 1, H});
+    Tensor fs = at::cat({fw.slice(2, 0, H).gather(1, last).view({B, H}), fw.select(1, 0).slice(1, H)}, 1);
+    Tensor f = VideoFuse::apply(video_features, prm[P_VE_W], prm[P_VE_B], prm[P_PE], fl(video_mask.reshape({B * Tn})), fs);
+
+    // ---- layout, part 2
+    TORCH_CHECK(hipEventSynchronize(count_ready) == hipSuccess, "hipEventSynchronize failed");
+    Layout lay;
+    lay.N = i32(host_n.const_data_ptr<int64_t>()[0]); lay.B = i32(B); lay.L = i32(L);
+    {
+        auto io = at::TensorOptions().dtype(at::kInt).device(dev);
+        Tensor mask8 = mm.contiguous().view(at::kByte);
+        lay.cells = at::empty({lay.N, 4}, io); lay.row_ptr = at::empty({B * L + 1}, io); lay.cellmap = at::empty({B, L, L}, io);
+        SMIN_CK(smin_build_cells(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), lay.B, lay.L, 0, lay.cells.data_ptr<int32_t>(),
+                                 lay.row_ptr.data_ptr<int32_t>(), lay.cellmap.data_ptr<int32_t>()));
+    }
+    const int64_t N = lay.N;
+    Tensor qmf = fl(qm), lmf = fl(length_mask);
+
+    // ---- parameter-only work on the second stream (SMIN._forward_stream in modules.py has the commentary)
+    HStream curs = c10::hip::getCurrentHIPStream(dev.index());
+    HStream side = overlap_boundary ? side_stream(dev.index()) : curs;
+    HStream prep = overlap_prep ? side : curs;
+    std::vector<Tensor> consts(nl), Pcat_first(nl);
+    std::vector<std::vector<Tensor>> Pcats(nl);
+    std::vector<Words> words(nl);
+    std::vector<std::pair<Tensor, Tensor>> mu_w(nl);
+    Tensor Wch_all, const_all;
+    wait_stream(prep, curs);
+    {
+        StreamScope sc(prep);
+        Tensor bsum;
+        for (int64_t k = 0; k < nl; ++k) {
+            consts[k] = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
+            bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
+        }
+        std::vector<Tensor> wch;
+        for (int64_t k = 0; k < nl; ++k) wch.push_back(lp(k, L_CH_W));
+        Wch_all = at::cat(wch);
+        const_all = consts[0];
+        for (int64_t k = 0; k < nl; ++k) {
+            Words& w = words[k];
+            w.what = at::linear(fw, lp(k, L_WH_W), lp(k, L_WH_B)) * qmf.unsqueeze(-1);
+            w.shat = at::linear(fs, lp(k, L_SH_W), lp(k, L_SH_B));
+            Tensor kb = at::linear(w.what, lp(k, L_AK_W), lp(k, L_AK_B));
+            w.Mq = at::matmul(kb, lp(k, L_AQ_W));
+            w.uq = at::matmul(kb, lp(k, L_AQ_B));
+            for (int64_t lo = 0; lo < k; lo += 4) {
+                std::vector<Tensor> parts;
+                for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
+                Pcats[k].push_back(at::cat(parts, 1));
+            }
+            mu_w[k] = {at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1), lp(k, L_FB_B) + lp(k, L_FC_B)};
+        }
+    }
+    wait_stream(curs, prep);
+    if (prep != curs) {
+        record_stream(Wch_all, curs);
+        for (int64_t k = 0; k < nl; ++k) {
+            record_stream(consts[k], curs);
+            record_stream(words[k].Mq, curs); record_stream(words[k].uq, curs); record_stream(words[k].what, curs); record_stream(words[k].shat, curs);
+            for (auto& p : Pcats[k]) record_stream(p, curs);
+            record_stream(mu_w[k].first, curs); record_stream(mu_w[k].second, curs);
+        }
+    }
+    if (side != curs) {
+        for (const Tensor* t : {&fw, &fs, &qmf, &lmf, &lay.cells, &lay.row_ptr, &lay.cellmap}) record_stream(*t, side);
+    }
+
+    auto pmv = ProposalMeans::apply(f, lay.cells, lay.row_ptr, lay.cellmap, N, T, L, C);
+    Tensor fm = pmv[0], fb = pmv[1];
+    const std::optional<Tensor> none;
+    Tensor g_all = LinearRows::apply(Wch_all, none, none, none, 1, at::TensorList{f.reshape({-1, D})});
+    auto pgs = ClipWindowMeans::apply(g_all.view({B, T, -1}), const_all, lay.cells, lay.row_ptr, lay.cellmap, N, T, L, C, nl);
+
+    Tensor cumean, Hs, Hsum;
+    std::vector<Tensor> hist;
+    for (int64_t k = 0; k < nl; ++k) {
+        const bool lastl = k == nl - 1;
+        const int64_t n_hbar = lastl ? 2 : ((k > 0 || nl < 3) ? 3 : 4);
+        auto views = Gate::apply(fm, fs, lay.cells, lay.row_ptr, B, L, n_hbar, k == 0 ? 2 : 1);
+        Tensor hbar_c = views[0], hbar_b = views[1], fm_res = views[n_hbar];
+        if (k == 0) cumean = views[n_hbar + 1];                          // mean_c f_c of the proposal map is f_m
+        // boundary unit on the second stream beside the content stream; joins before the moment unit
+        Tensor bu;
+        wait_stream(side, curs);
+        {
+            StreamScope sc(side);
+            bu = BoundaryUnitFn::apply(fb, fw, fs, hbar_b, lp(k, L_BQ_W), lp(k, L_BQ_B), lp(k, L_BK_W), lp(k, L_BK_B), qmf, lmf, lay.cells, lay.row_ptr, N);
+        }
+        if (side != curs) { record_stream(fb, side); record_stream(hbar_b, side); }
+        const Tensor& Wch = lp(k, L_CH_W);
+        Tensor chat = pgs[k];
+        for (size_t part = 0, lo = 0; lo < hist.size(); ++part, lo += 4) {
+            std::optional<Tensor> hp;
+            if (lo == 0) hp = LinearRows::apply(Wch, none, none, none, 1, at::TensorList{Hs});
+            std::vector<Tensor> xs(hist.begin() + lo, hist.begin() + std::min(lo + 4, hist.size()));
+            chat = LinearRows::apply(Pcats[k][part], lo == 0 ? std::optional<Tensor>(consts[k]) : none, std::optional<Tensor>(chat), hp, C, at::TensorList(xs));
+        }
+        const Words& w = words[k];
+        auto ca = ContentAttn::apply(chat, w.Mq, w.uq, w.what, w.shat, qmf, lay.cells, lay.row_ptr, N, L, C, !lastl);
+        Tensor cc = ca[0], ccmean = ca[1];
+        cumean = LinearRows::apply(lp(k, L_C_W), std::optional<Tensor>(lp(k, L_C_B)), std::optional<Tensor>(cumean), std::optional<Tensor>(hbar_c), 1, at::TensorList{ccmean});
+        if (!lastl) {
+            if (!Hs.defined()) { Hs = views[2]; Hsum = n_hbar > 3 ? views[3] : views[2]; }
+            else { Hs = Hsum + views[2]; Hsum = Hs; }
+            hist.push_back(cc);
+        }
+        wait_stream(curs, side);
+        if (side != curs) record_stream(bu, curs);
+        auto mu = MomentUnitFn::apply(cumean, fm_res, bu, mu_w[k].first, mu_w[k].second, lay.cells, lay.row_ptr, lay.cellmap);
+        fm = mu[0]; cumean = mu[1];
+        fb = bu;
+    }
+    // Localization (models.py:335-344)
+    Tensor wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
+    Tensor bb = at::cat({loc[3], loc[5], loc[7]});
+    auto sc = ScoreMap::apply(fm, fb, loc[0].view({D}), loc[1], wb, bb, lmf, lay.cells);
+    Tensor psea = sc[1];
+    return std::make_tuple(sc[0], psea[0], psea[1], psea[2]);
+}
+
+Tensor smin_loss(const Tensor& pm, const Tensor& ym, const Tensor& sm, const Tensor& moment_mask, const Tensor& ps, const Tensor& ys, const Tensor& ss, const Tensor& pe,
+                 const Tensor& ye, const Tensor& se, const Tensor& pa, const Tensor& ya, const Tensor& length_mask)
+{
+    TORCH_CHECK(pm.is_cuda(), "smin_loss runs on a HIP device only (there is no CPU fallback)");
+    c10::hip::HIPGuard device_guard(pm.device().index());
+    return LossNode::apply(pm, ps, pe, pa, ym, sm, moment_mask, ys, ss, ye, se, ya, length_mask);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(smin_hip, m)
+{
+    // SMIN.forward (reference models.py:367-377): the six forward arguments, the parameters in SMIN._native_params order and
+    // cfg = [T, L, C, D, dl, num_smi_layers, max_query_length, lstm_hidden_size, overlap_boundary, overlap_prep]
+    m.def("smin_forward(Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask, Tensor moment_mask, "
+          "Tensor[] params, int[] cfg) -> (Tensor, Tensor, Tensor, Tensor)", &smin_forward);
+    // restated loss_fn of the reference's train loop (main.py:110-116), same argument order
+    m.def("smin_loss(Tensor pm, Tensor ym, Tensor sm, Tensor moment_mask, Tensor ps, Tensor ys, Tensor ss, Tensor pe, Tensor ye, Tensor se, Tensor pa, Tensor ya, "
+          "Tensor length_mask) -> Tensor", &smin_loss);
+    m.def("abi_version() -> int", []() -> int64_t { return smin_abi_version(); });
+}

@@ -406,6 +406,7 @@ class SMIN(nn.Module):
         self.smis = nn.ModuleList([SMI(D, dl) for _ in range(num_smi_layers)])
         self.localization = Localization(D)
 
+    native_host = True             # run the in-model path as ONE torch-extension call (csrc/torch_binding.cpp); False: Python host
     content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
     overlap_boundary = True        # boundary unit on a second HIP stream beside the content stream
     overlap_prep = True            # parameter-only work (word-side operands, weight products) on that stream as well
@@ -502,8 +503,41 @@ class SMIN(nn.Module):
             fb = bu
         return self.localization.forward_packed(fm, fb, length_mask, layout)
 
+    def _native_params(self):
+        """Parameters in the order csrc/torch_binding.cpp reads them: video encoder 3, LSTM 16, 20 per SMI layer, localization 8."""
+        ve, lstm = self.backbone.videoencoder, self.backbone.queryencoder.lstm
+        ps = [ve.ve.weight, ve.ve.bias, ve.pe.weight]
+        for layer in range(2):
+            for sfx in ("", "_reverse"):
+                ps += [getattr(lstm, f"{n}_l{layer}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        for smi in self.smis:
+            cu, bu, mu = smi.content_unit, smi.boundary_unit.attn_layer, smi.moment_unit
+            for m in (cu.linear_c_hat, cu.linear_w_hat, cu.linear_s_hat, cu.linear_c, cu.attn_layer.W_q, cu.attn_layer.W_k, bu.W_q, bu.W_k,
+                      mu.conv_layer_fb, mu.conv_layer_fc):
+                ps += [m.weight, m.bias]
+        lo = self.localization
+        for m in (lo.conv_layer_pm, lo.conv_layer_ps, lo.conv_layer_pe, lo.conv_layer_pa):
+            ps += [m.weight, m.bias]
+        return ps
+
+    def _native_ok(self, video_features, query_features):
+        """The torch-extension path covers the production configuration: content stream on a mask-driven cell list, fused
+        BiLSTM and video encoder kernels.  Anything else (dl >= D, C outside 2..4, > 8 layers, H > 256, odd widths) runs the
+        same kernels from the Python host below."""
+        H, ve, nl = self.lstm_hidden_size, self.backbone.videoencoder, len(self.smis)
+        return (self.native_host and self.content_stream and self.dl < self.D and 2 <= self.C <= 4 and 1 <= nl <= 8 and nl * self.dl <= 2048
+                and self.backbone.queryencoder.fused_lstm and H <= 256 and H % 4 == 0
+                and video_features.dtype == torch.float32 and query_features.dtype == torch.float32 and ve.d0 % 4 == 0 and ve.d % 4 == 0
+                and video_features.shape[1] == self.T and video_features.shape[1] <= ve.pe.weight.shape[0])
+
     @_hip_forward
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
+        if self._native_ok(video_features, query_features):
+            from . import _lib
+            cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
+                   int(self.overlap_boundary), int(self.overlap_prep)]
+            return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
+                                                  self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
         f, fs, fw = self.backbone(video_features, video_mask, query_features, query_mask)
         layout = pending.finish()                                  # the only host sync of a step; hidden behind the backbone

@@ -27,6 +27,9 @@ def loss_fn_torch(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, lengt
             + bce_loss(pe, ye, se, length_mask) + 0.5 * bce_loss(pa, ya, None, length_mask))
 
 
+NATIVE_LOSS = True          # loss through the torch-extension binding (False: the ctypes / Python autograd host, same kernels)
+
+
 def _require_hip(t, what):
     if not t.is_cuda:
         from ._lib import SminHipError
@@ -38,6 +41,9 @@ def loss_fn(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask
     """reference main.py:110-116 (same argument order): one fused forward and one fused backward kernel
     (functional.LossFn, csrc/loss.hip) instead of ~40 element-wise launches.  HIP tensors only."""
     _require_hip(pm, "loss_fn")
+    from . import _lib
+    if NATIVE_LOSS:
+        return _lib.load_torch().smin_loss(pm, ym, sm, moment_mask, ps, ys, ss, pe, ye, se, pa, ya, length_mask)
     from .functional import LossFn
     with torch.cuda.device(pm.device):
         return LossFn.apply(pm, ps, pe, pa, ym, sm, moment_mask, ys, ss, ye, se, ya, length_mask)
