@@ -114,6 +114,27 @@ __device__ __forceinline__ void chunk_rows_f4(const float* Ws, int row0, int col
         if (c4 < ncols && row < M && col < N) f(row, col, ldg4(Ws + r * GEMM_LDW + c4));
     }
 }
+// Two-phase visit for epilogues that add tensors from HBM: pre(row, col) -> A requests an element's addends (called for all
+// eight elements of the lane first, unconditionally, with clamped indices), post(row, col, v, a) consumes them.  With a
+// single-phase lambda the loads of element k+1 sit behind the store of element k (hipcc cannot move a load above a store
+// through unrelated pointers), so a chunk paid eight HBM round trips in a row: K = 128 contractions with a residual ran at
+// 36 TF against 97 TF for the same shape with a plain store.
+template <class A, class PRE, class POST>
+__device__ __forceinline__ void chunk_rows_f4_pre(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane, PRE pre, POST post)
+{
+    A add[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = lane + 64 * it, r = idx >> 4, c4 = (idx & 15) * 4;
+        add[it] = pre(min(row0 + r, M - 1), min(col0 + c4, N - 4));
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = lane + 64 * it, r = idx >> 4, c4 = (idx & 15) * 4;
+        const int row = row0 + r, col = col0 + c4;
+        if (c4 < ncols && row < M && col < N) post(row, col, ldg4(Ws + r * GEMM_LDW + c4), add[it]);
+    }
+}
 // Same chunk as 8 groups of 4 consecutive rows (row0 % 4 == 0): f(first_row, col, v[4]) -- one lane owns the 4 clips of a cell.
 template <class F>
 __device__ __forceinline__ void chunk_quads_f4(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane, F f)

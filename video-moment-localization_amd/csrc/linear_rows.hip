@@ -9,13 +9,19 @@ namespace smin {
 
 struct EpLinearRows {
     const float* bias; const float* add_rows; const float* add_cells; int C; float* out;
+    struct Add { float4 r, c; };
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
-        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
-            if (bias) v = f4add(v, ldg4(bias + col));
-            if (add_rows) v = f4add(v, ldg4(add_rows + (size_t)row * N + col));
-            if (add_cells) v = f4add(v, ldg4(add_cells + (size_t)(row / C) * N + col));
-            stg4(out + (size_t)row * N + col, v);
-        });
+        chunk_rows_f4_pre<Add>(Ws, row0, col0, ncols, M, N, lane,
+            [&](int row, int col) {
+                Add a;
+                a.r = add_rows ? ldg4(add_rows + (size_t)row * N + col) : f4zero();
+                a.c = add_cells ? ldg4(add_cells + (size_t)(row / C) * N + col) : f4zero();
+                return a;
+            },
+            [&](int row, int col, float4 v, const Add& a) {
+                if (bias) v = f4add(v, ldg4(bias + col));
+                stg4(out + (size_t)row * N + col, f4add(f4add(v, a.r), a.c));
+            });
     }
 };
 struct EpStoreRows {

@@ -9,22 +9,25 @@ namespace smin {
 
 struct EpMomentOut {                // mu = (acc + bcat) * m + fm
     const float* bcat; const int* cells; const float* fm; float* out;
+    struct Add { float4 r; float m; };
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
-        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
-            const float m = (float)cells[4 * (size_t)row + 3];
-            stg4(out + (size_t)row * N + col, f4add(f4scale(f4add(v, ldg4(bcat + col)), m), ldg4(fm + (size_t)row * N + col)));
-        });
+        chunk_rows_f4_pre<Add>(Ws, row0, col0, ncols, M, N, lane,
+            [&](int row, int col) { return Add{ldg4(fm + (size_t)row * N + col), (float)cells[4 * (size_t)row + 3]}; },
+            [&](int row, int col, float4 v, const Add& a) {
+                stg4(out + (size_t)row * N + col, f4add(f4scale(f4add(v, ldg4(bcat + col)), a.m), a.r));
+            });
     }
 };
 
 struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradient), [D, 2D) -> dfcmean (+ acc: another
     float* dx1; float* dmean; int D; const float* acc;       //  consumer's gradient of fcmean, summed here)
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
-        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
-            if (col < D) { stg4(dx1 + (size_t)row * D + col, v); return; }
-            const size_t o = (size_t)row * D + (col - D);
-            stg4(dmean + o, acc ? f4add(v, ldg4(acc + o)) : v);
-        });
+        chunk_rows_f4_pre<float4>(Ws, row0, col0, ncols, M, N, lane,
+            [&](int row, int col) { return (acc && col >= D) ? ldg4(acc + (size_t)row * D + (col - D)) : f4zero(); },
+            [&](int row, int col, float4 v, const float4& a) {
+                if (col < D) { stg4(dx1 + (size_t)row * D + col, v); return; }
+                stg4(dmean + (size_t)row * D + (col - D), f4add(v, a));
+            });
     }
 };
 
