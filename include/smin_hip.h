@@ -189,8 +189,17 @@ int smin_loss_bwd(void* stream, const float* dloss, const float* part,
                   const float* pa, const uint8_t* ya, const uint8_t* lm, int B, int L,
                   float* dpm, float* dps, float* dpe, float* dpa);
 
+/* ---- masks and training targets of a batch (reference dataset.py:95-155: AbstractDataset.get_iou, get_boundary_penalties,
+ * get_snippet_label and the mask construction of __getitem__, per sample on the host there).
+ * times [B][2] = ground-truth (start, end) seconds, duration [B], nfeats [B] sampled frames (clamped to T), qlen [B] query
+ * words.  Outputs (bytes are 0/1): video_mask [B][T], query_mask [B][Nq] (NULL with qlen NULL: not wanted), length_mask [B][L],
+ * moment_mask [B][L][L], sm [B][L][L] fp32, ym, ss / se [B][L] fp32, ys, ye, ya.  Requires L | T. */
+int smin_build_targets(void* stream, const float* times, const float* duration, const int32_t* nfeats, const int32_t* qlen, int B, int T, int L, int Nq,
+                       uint8_t* video_mask, uint8_t* query_mask, uint8_t* length_mask, uint8_t* moment_mask, float* sm, uint8_t* ym,
+                       float* ss, uint8_t* ys, float* se, uint8_t* ye, uint8_t* ya);
+
 /* ---- compute_ious (reference utils.py:10-31): counts [8] = number of samples with a hit for
- * R@1 x IoU {0.1, 0.3, 0.5, 0.7} then R@5 x the same; ws [B][8] scratch; L*L*4 bytes of LDS per sample (L <= 196). */
+ * R@1 x IoU {0.1, 0.3, 0.5, 0.7} then R@5 x the same; ws [B][8] scratch.  Any L with L*L >= 5 (the reference's topk(5) needs as many). */
 int smin_compute_ious(void* stream, const float* pm, const float* ps, const float* pe, const uint8_t* mm, const float* sm,
                       int B, int L, float* counts, float* ws);
 

@@ -275,6 +275,69 @@ def test_native_host_equals_python_host(dev):
             assert torch.equal(g1[k], g2[k]), k
 
 
+def test_target_kernel_and_feeder(dev):
+    """csrc/labels.hip (one launch for every mask / target of a batch) against the per-sample restatement of dataset.py:95-155
+    and the torch form; then the double-buffered BatchFeeder: what it yields equals direct construction, batch after batch, and
+    feeds SMIN.  PARITY UNPINNED for the targets (dataset.py is not importable here; the reference holds no fixtures for them)."""
+    import models
+    from oracle import labels_oracle as LO
+    V = models.vml_amd
+    g = torch.Generator().manual_seed(5)
+    for (T, L, Nq, B) in [(256, 64, 20, 7), (1024, 512, 20, 2), (64, 16, 13, 6)]:
+        dur = torch.rand(B, generator=g) * 200 + 5
+        ts = torch.rand(B, generator=g) * dur * 0.6
+        te = ts + torch.rand(B, generator=g) * (dur - ts) * 0.9 + 0.5
+        nf = torch.randint(3, 2 * T, (B,), generator=g)
+        ql = torch.randint(1, Nq + 1, (B,), generator=g)
+        times = torch.stack([ts, te], 1)
+        got = V.build_targets_hip(times.to(dev), dur.to(dev), nf.to(dev), ql.to(dev), T, L, Nq)
+        ref_t = V.build_targets(times.to(dev), dur.to(dev), nf.to(dev), T, L, device=dev)
+        assert got["video_mask"].dtype == torch.uint8 and got["video_mask"].shape == (B, T, 1) and got["query_mask"].shape == (B, Nq, 1)
+        assert got["moment_mask"].dtype == torch.bool and got["length_mask"].dtype == torch.bool
+        assert torch.equal(got["query_mask"].reshape(B, Nq).cpu(), (torch.arange(Nq).unsqueeze(0) < ql.unsqueeze(1)).to(torch.uint8))
+        for k, v in ref_t.items():
+            if v.dtype.is_floating_point:
+                assert torch.allclose(got[k], v, rtol=1e-5, atol=1e-6, equal_nan=True), (T, L, k)
+        for b in range(B):
+            ref = LO.sample_targets(float(ts[b]), float(te[b]), float(dur[b]), int(nf[b]), T, L)
+            for k, v in ref.items():
+                a = got[k][b].cpu()
+                if v.dtype.is_floating_point:
+                    assert torch.allclose(a, v, rtol=1e-5, atol=1e-6, equal_nan=True), (T, L, b, k)
+                else:                                     # labels are thresholds of fp32 scores: allow a flip only where the score sits on 0.5
+                    a, v = a.to(v.dtype).reshape(v.shape), v
+                    if not torch.equal(a, v):
+                        src = {"ym": "sm", "ys": "ss", "ye": "se"}.get(k)
+                        assert src is not None, (T, L, b, k)
+                        assert ((ref[src][a != v] - 0.5).abs() < 1e-5).all(), (T, L, b, k)
+    # the feeder
+    T, L, Nq, Din, B = 64, 16, 9, 40, 4
+    hbs = []
+    for s in range(5):
+        dur = torch.rand(B, generator=g) * 100 + 5
+        ts = torch.rand(B, generator=g) * dur * 0.5
+        te = ts + 1.0 + torch.rand(B, generator=g) * (dur - ts - 1.0).clamp(min=0)
+        hbs.append(dict(video_features=torch.randn(B, T, Din, generator=g).numpy(), query_features=torch.randn(B, Nq, 300, generator=g),
+                        nfeats=torch.randint(T // 2, T + 1, (B,), generator=g), qlen=torch.randint(2, Nq + 1, (B,), generator=g),
+                        times=torch.stack([ts, te], 1), duration=dur))
+    feeder = V.BatchFeeder(T, L, Nq, dev)
+    m = models.SMIN(T, L, 4, 64, 32, 2, Din, Nq, 32, dev).to(dev)
+    n = 0
+    for hb, fed in zip(hbs, feeder.feed(hbs)):
+        n += 1
+        assert list(fed.keys()) == ["video_features", "video_mask", "query_features", "query_mask", "length_mask", "moment_mask", "sm", "ym", "ss", "ys", "se", "ye", "ya"]
+        want = V.build_targets_hip(torch.as_tensor(hb["times"]).to(dev), hb["duration"].to(dev), hb["nfeats"].to(dev), hb["qlen"].to(dev), T, L, Nq)
+        assert torch.equal(fed["video_features"].cpu(), torch.as_tensor(hb["video_features"]))
+        assert torch.equal(fed["query_features"].cpu(), hb["query_features"])
+        for k, v in want.items():
+            assert torch.equal(torch.nan_to_num(fed[k].float()), torch.nan_to_num(v.float())), k
+        out = m(*H.model_inputs(fed))
+        loss = V.loss_fn(out[0], fed["ym"], torch.nan_to_num(fed["sm"]), fed["moment_mask"], out[1], fed["ys"], fed["ss"], out[2], fed["ye"], fed["se"], out[3],
+                         fed["ya"], fed["length_mask"])
+        assert torch.isfinite(loss)
+    assert n == 5
+
+
 # ---------------------------------------------------------------- size-independent properties at BASELINE size
 def test_properties_full_size(dev):
     from oracle import smin_oracle as O

@@ -17,3 +17,4 @@ from .modules import (  # noqa: F401
 )
 from .training import loss_fn, loss_fn_torch, bce_loss, compute_ious, compute_ious_torch  # noqa: F401
 from .labels import build_targets  # noqa: F401
+from .feeder import BatchFeeder, build_targets_hip  # noqa: F401

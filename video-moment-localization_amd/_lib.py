@@ -41,6 +41,7 @@ SIGNATURES = {
     "smin_loss_fwd": [_vp] * 14 + [_i] * 2 + [_vp] * 2,
     "smin_loss_bwd": [_vp] * 16 + [_i] * 2 + [_vp] * 4,
     "smin_compute_ious": [_vp] * 6 + [_i] * 2 + [_vp] * 2,
+    "smin_build_targets": [_vp] * 5 + [_i] * 4 + [_vp] * 11,
     "smin_build_cells": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
