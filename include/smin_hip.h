@@ -248,6 +248,21 @@ int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, 
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
 int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 
+/* ---- word-side operands of every layer's content attention in one launch (ContentUnit.forward models.py:249-251 and the
+ * word half of ContentAttention.forward models.py:209-211, with W_q folded onto the words).  Per layer k:
+ *   what_k = (f_w WH_k^T + bWH_k) * qmask,  shat_k = f_s SH_k^T + bSH_k,  kb_k = what_k AK_k^T + bAK_k,  Mq_k = kb_k AQ_k,  uq_k = kb_k . bAQ_k
+ * params: HOST array of nl*8 device pointers, per layer [WH (dl,D), bWH, SH (dl,D), bSH, AK (dl,dl), bAK, AQ (dl,dl), bAQ]
+ * (= linear_w_hat, linear_s_hat, attn_layer.W_k, attn_layer.W_q).  fw [B][Nq][D], fs [B][D], qmask [B][Nq] fp32.
+ * Outputs, layer-major: what, kb, Mq [nl][B][Nq][dl], shat [nl][B][dl], uq [nl][B][Nq].  nl <= 8, Nq <= 32, dl <= 128. */
+int smin_word_prep_fwd(void* stream, const float* fw, const float* fs, const float* qmask, const float* const* params, int nl, int B, int Nq, int D,
+                       int dl, float* what, float* shat, float* kb, float* Mq, float* uq);
+size_t smin_word_prep_bwd_workspace_bytes(int nl, int B, int Nq, int D, int dl);
+/* dwhat / dshat / dMq / duq: HOST arrays of nl device pointers (per-layer gradients [B][..]; NULL entries = zero).
+ * -> dfw [B][Nq][D], dfs [B][D], dparams: HOST array of nl*8 device pointers (same order as params), all written. */
+int smin_word_prep_bwd(void* stream, const float* const* dwhat, const float* const* dshat, const float* const* dMq, const float* const* duq,
+                       const float* fw, const float* fs, const float* qmask, const float* what, const float* kb, const float* const* params,
+                       int nl, int B, int Nq, int D, int dl, float* dfw, float* dfs, float* const* dparams, void* ws, size_t ws_bytes);
+
 /* ---- VideoEncoder (models.py:25-36) fused with the backbone's Hadamard product (models.py:81-83):
  *   fv[b][t][:] = (x[b][t][:] W^T + bias + pe[t][:]) * vmask[b][t]     f[b][t][:] = fv[b][t][:] * fs[b][:]
  * x [B*T][Din], W [D][Din], pe [>=T][D] (rows 0..T-1 are used), vmask [B*T] fp32, fs [B][D]; outputs fv, f [B*T][D]. */

@@ -42,6 +42,9 @@ SIGNATURES = {
     "smin_loss_bwd": [_vp] * 16 + [_i] * 2 + [_vp] * 4,
     "smin_compute_ious": [_vp] * 6 + [_i] * 2 + [_vp] * 2,
     "smin_build_targets": [_vp] * 5 + [_i] * 4 + [_vp] * 11,
+    "smin_word_prep_fwd": [_vp] * 5 + [_i] * 5 + [_vp] * 5,
+    "smin_word_prep_bwd_workspace_bytes": [_i] * 5,
+    "smin_word_prep_bwd": [_vp] * 11 + [_i] * 5 + [_vp] * 3 + [_vp, _sz],
     "smin_build_cells": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -64,7 +67,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
             "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz,
-            "smin_bilstm_layer_bwd_workspace_bytes": _sz, "smin_video_encoder_bwd_workspace_bytes": _sz}
+            "smin_bilstm_layer_bwd_workspace_bytes": _sz, "smin_video_encoder_bwd_workspace_bytes": _sz, "smin_word_prep_bwd_workspace_bytes": _sz}
 
 _lib = None
 _ws = {}

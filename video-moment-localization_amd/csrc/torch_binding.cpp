@@ -372,6 +372,51 @@ struct LinearRows : torch::autograd::Function<LinearRows> {
     }
 };
 
+// word-side operands of every layer's content attention in one launch (models.py:249-251, 209-211; csrc/word_prep.hip):
+// params = 8 per layer (linear_w_hat, linear_s_hat, attn_layer.W_k, attn_layer.W_q: weight, bias); returns (what, shat, Mq, uq) per layer
+struct WordPrep : torch::autograd::Function<WordPrep> {
+    static variable_list forward(AutogradContext* ctx, Tensor fw, Tensor fs, Tensor qmask, at::TensorList params_in)
+    {
+        fw = cont(fw); fs = cont(fs); qmask = cont(qmask);
+        std::vector<Tensor> params;
+        std::vector<const float*> pp;
+        for (const Tensor& p : params_in) { params.push_back(cont(p)); pp.push_back(fp(params.back())); }
+        const int nl = i32(params.size() / 8), B = i32(fw.size(0)), Nq = i32(fw.size(1)), D = i32(fw.size(2)), dl = i32(params[0].size(0));
+        Tensor what = at::empty({nl, B, Nq, dl}, fw.options()), kb = at::empty({nl, B, Nq, dl}, fw.options()), Mq = at::empty({nl, B, Nq, dl}, fw.options());
+        Tensor shat = at::empty({nl, B, dl}, fw.options()), uq = at::empty({nl, B, Nq}, fw.options());
+        SMIN_CK(smin_word_prep_fwd(cur(), fp(fw), fp(fs), fp(qmask), pp.data(), nl, B, Nq, D, dl, fpm(what), fpm(shat), fpm(kb), fpm(Mq), fpm(uq)));
+        variable_list save{fw, fs, qmask, what, kb};
+        for (auto& p : params) save.push_back(p);
+        ctx->save_for_backward(save);
+        variable_list outs;
+        for (int k = 0; k < nl; ++k) { outs.push_back(what[k]); outs.push_back(shat[k]); outs.push_back(Mq[k]); outs.push_back(uq[k]); }
+        return outs;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &fw = sv[0], &fs = sv[1], &qmask = sv[2], &what = sv[3], &kb = sv[4];
+        const int nl = i32((sv.size() - 5) / 8), B = i32(fw.size(0)), Nq = i32(fw.size(1)), D = i32(fw.size(2)), dl = i32(sv[5].size(0));
+        std::vector<Tensor> keep;
+        std::vector<const float*> gp[4], pp;
+        for (int k = 0; k < nl; ++k)
+            for (int j = 0; j < 4; ++j) {
+                const Tensor& t = g[4 * k + j];
+                if (t.defined()) { keep.push_back(cont(t)); gp[j].push_back(fp(keep.back())); } else gp[j].push_back(nullptr);
+            }
+        Tensor dfw = at::empty_like(fw), dfs = at::empty_like(fs);
+        std::vector<Tensor> dparams;
+        std::vector<float*> dp;
+        for (int i = 0; i < nl * 8; ++i) { pp.push_back(fp(sv[5 + i])); dparams.push_back(at::empty_like(sv[5 + i])); dp.push_back(fpm(dparams.back())); }
+        auto ws = scratch(smin_word_prep_bwd_workspace_bytes(nl, B, Nq, D, dl), fw.device());
+        SMIN_CK(smin_word_prep_bwd(cur(), gp[0].data(), gp[1].data(), gp[2].data(), gp[3].data(), fp(fw), fp(fs), fp(qmask), fp(what), fp(kb), pp.data(), nl, B, Nq, D, dl,
+                                   fpm(dfw), fpm(dfs), dp.data(), ws.p, ws.n));
+        variable_list out{dfw, dfs, undef()};
+        for (auto& t : dparams) out.push_back(t);
+        return out;
+    }
+};
+
 // hbar = sigmoid(fm * fs) * fm (models.py:191, 272-274), n_hbar views of it followed by n_res views of fm: every
 // consumer gets its own view so that the one backward kernel sums their gradients
 struct Gate : torch::autograd::Function<Gate> {
@@ -621,13 +666,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
         for (int64_t k = 0; k < nl; ++k) wch.push_back(lp(k, L_CH_W));
         Wch_all = at::cat(wch);
         const_all = consts[0];
+        {
+            std::vector<Tensor> wp;                               // every layer's word-side operands in one launch
+            for (int64_t k = 0; k < nl; ++k)
+                for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) wp.push_back(lp(k, which));
+            auto wo = WordPrep::apply(fw, fs, qmf, at::TensorList(wp));
+            for (int64_t k = 0; k < nl; ++k) { words[k].what = wo[4 * k]; words[k].shat = wo[4 * k + 1]; words[k].Mq = wo[4 * k + 2]; words[k].uq = wo[4 * k + 3]; }
+        }
         for (int64_t k = 0; k < nl; ++k) {
-            Words& w = words[k];
-            w.what = at::linear(fw, lp(k, L_WH_W), lp(k, L_WH_B)) * qmf.unsqueeze(-1);
-            w.shat = at::linear(fs, lp(k, L_SH_W), lp(k, L_SH_B));
-            Tensor kb = at::linear(w.what, lp(k, L_AK_W), lp(k, L_AK_B));
-            w.Mq = at::matmul(kb, lp(k, L_AQ_W));
-            w.uq = at::matmul(kb, lp(k, L_AQ_B));
             for (int64_t lo = 0; lo < k; lo += 4) {
                 std::vector<Tensor> parts;
                 for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));

@@ -230,6 +230,51 @@ class LinearRowsFn(Function):
         return (dW, dbias, (dy if need[2] else None), dcells, None) + (tuple(dxs) if want_dx else (None,) * nseg)
 
 
+def _ptr_array_opt(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class WordPrepFn(Function):
+    """Word-side operands of every layer's content attention in one launch (reference models.py:249-251, 209-211):
+    ``WordPrepFn.apply(fw, fs, qmask, *params)`` with 8 parameters per layer (linear_w_hat.{weight,bias}, linear_s_hat.{..},
+    attn_layer.W_k.{..}, attn_layer.W_q.{..}) returns (what_k, shat_k, Mq_k, uq_k) for every layer, flattened."""
+
+    @staticmethod
+    def forward(ctx, fw, fs, qmask, *params):
+        fw, fs, qmask = _c(fw), _c(fs), _c(qmask)
+        params = tuple(_c(p) for p in params)
+        nl = len(params) // 8
+        B, Nq, D = fw.shape
+        dl = params[0].shape[0]
+        what, kb, Mq = (fw.new_empty((nl, B, Nq, dl)) for _ in range(3))
+        shat, uq = fw.new_empty((nl, B, dl)), fw.new_empty((nl, B, Nq))
+        for p in params:
+            ptr(p)
+        call("smin_word_prep_fwd", stream(), ptr(fw), ptr(fs), ptr(qmask), _ptr_array(params), nl, B, Nq, D, dl, ptr(what), ptr(shat), ptr(kb), ptr(Mq), ptr(uq))
+        ctx.save_for_backward(fw, fs, qmask, what, kb, *params)
+        outs = []
+        for k in range(nl):
+            outs += [what[k], shat[k], Mq[k], uq[k]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        fw, fs, qmask, what, kb, *params = ctx.saved_tensors
+        nl = len(params) // 8
+        B, Nq, D = fw.shape
+        dl = params[0].shape[0]
+        g = [None if x is None else _c(x) for x in grads]
+        for x in g:
+            ptr(x)
+        dfw, dfs = torch.empty_like(fw), torch.empty_like(fs)
+        dparams = [torch.empty_like(p) for p in params]
+        _, wp, wn = _ws(_lib.load().smin_word_prep_bwd_workspace_bytes(nl, B, Nq, D, dl), fw.device)
+        call("smin_word_prep_bwd", stream(), _ptr_array_opt(g[0::4]), _ptr_array_opt(g[1::4]), _ptr_array_opt(g[2::4]), _ptr_array_opt(g[3::4]),
+             ptr(fw), ptr(fs), ptr(qmask), ptr(what), ptr(kb), _ptr_array(params), nl, B, Nq, D, dl, ptr(dfw), ptr(dfs), _ptr_array(dparams), wp, wn)
+        return (dfw, dfs, None) + tuple(dparams)
+
+
 class VideoFuseFn(Function):
     """f = ((x W^T + b + pe[t]) * vmask) * f_s  -- VideoEncoder.forward and the backbone's Hadamard product (reference
     models.py:25-36, 81-83) as one contraction with a fused epilogue.  x [B, T, Din] (no gradient), pe [T_emb, D]."""

@@ -21,7 +21,7 @@ import torch.nn as nn
 from ._lib import SminHipError
 
 from .cells import CellLayout
-from .functional import (VideoFuseFn, BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
+from .functional import (VideoFuseFn, WordPrepFn, BiLstmLayerFn, BoundaryUnitFn, ClipWindowMeansFn, ContentAttnFn, ContentUnitFn, GateFn, LinearRowsFn, MomentUnitFn,
                          ProposalMapFn, ProposalMeansFn, ScoreMapFn)
 
 
@@ -289,15 +289,18 @@ class ContentUnit(nn.Module):
         self.linear_c = nn.Linear(dl, D)
         self.attn_layer = ContentAttention(dl)
 
+    def word_params(self):
+        """The eight parameters of the word side, in the order csrc/word_prep.hip reads them."""
+        at = self.attn_layer
+        return [self.linear_w_hat.weight, self.linear_w_hat.bias, self.linear_s_hat.weight, self.linear_s_hat.bias,
+                at.W_k.weight, at.W_k.bias, at.W_q.weight, at.W_q.bias]
+
     def word_operands(self, f_w, f_s, query_mask):
-        """Per-sample word-side operands of the attention core: (Mq, uq, what, shat, qmask rows)."""
+        """Per-sample word-side operands of the attention core: (Mq, uq, what, shat, qmask rows) -- one HIP launch
+        (csrc/word_prep.hip): what = linear_w_hat(f_w) * qmask, shat = linear_s_hat(f_s), kb = W_k(what), and the clip side's W_q
+        folded onto the words, W_q(c_hat) . kb^T == c_hat . (kb W_q.weight)^T + kb . W_q.bias = c_hat . Mq^T + uq."""
         qm = _rows(query_mask)
-        what = self.linear_w_hat(f_w) * qm.unsqueeze(-1)
-        shat = self.linear_s_hat(f_s)
-        kb = self.attn_layer.W_k(what)
-        # W_q(c_hat) . kb^T == c_hat . (kb W_q.weight)^T + kb . W_q.bias : the per-cell dl x dl projection folds away
-        Mq = torch.matmul(kb, self.attn_layer.W_q.weight)
-        uq = torch.matmul(kb, self.attn_layer.W_q.bias)
+        what, shat, Mq, uq = WordPrepFn.apply(f_w, f_s, qm, *self.word_params())
         return Mq, uq, what, shat, qm
 
     def forward_packed(self, fc, hbar, f_w, f_s, query_mask, layout, fcmean_in=None):
@@ -443,7 +446,9 @@ class SMIN(nn.Module):
             # layer 0's constant rides on the clip means; later layers get theirs in the contraction that forms chat_k,
             # whose weight-gradient pass yields the constant's gradient (a column sum) for free
             const_all = consts[0]
-            words = [cu.word_operands(fw, fs, query_mask) for cu in cus]
+            qmr = _rows(query_mask)                                       # every layer's word-side operands in one launch
+            wo = WordPrepFn.apply(fw, fs, qmr, *[p for cu in cus for p in cu.word_params()])
+            words = [(wo[4 * k + 2], wo[4 * k + 3], wo[4 * k], wo[4 * k + 1], qmr) for k in range(nl)]
             Pcats = [[torch.cat([torch.matmul(cus[k].linear_c_hat.weight, cus[l].linear_c.weight) for l in range(lo, min(lo + 4, k))], dim=1)
                       for lo in range(0, k, 4)] for k in range(nl)]
             mu_w = [smi.moment_unit.cat_weights() for smi in self.smis]
