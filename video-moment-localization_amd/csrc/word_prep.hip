@@ -71,36 +71,40 @@ __device__ __forceinline__ void rows_mat(const float* in, int ldi, int nrows, co
 
 __global__ __launch_bounds__(256)
 void word_prep_fwd_kernel(const float* __restrict__ fw, const float* __restrict__ fs, const float* __restrict__ qmask, WordParams P,
-                          int B, int Nq, int D, int dl, float* __restrict__ what, float* __restrict__ shat, float* __restrict__ kb,
+                          int B, int Nq, int D, int dl, int rpp, float* __restrict__ what, float* __restrict__ shat, float* __restrict__ kb,
                           float* __restrict__ Mq, float* __restrict__ uq)
 {
+    // grid (B, layers, row parts): every stage is row-wise, so a sample's words are cut into parts of rpp rows -- small batches
+    // still fill the chip (tacos.yml: 2 samples x 3 layers would be 6 workgroups)
     extern __shared__ __attribute__((aligned(16))) float wp_smem[];
     const int b = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+    const int r0 = blockIdx.z * rpp, nr = min(Nq, r0 + rpp) - r0;
+    if (nr <= 0) return;
     const float *WH = P.p[8 * k], *bWH = P.p[8 * k + 1], *SH = P.p[8 * k + 2], *bSH = P.p[8 * k + 3], *AK = P.p[8 * k + 4], *bAK = P.p[8 * k + 5],
                 *AQ = P.p[8 * k + 6], *bAQ = P.p[8 * k + 7];
-    float* fwS = wp_smem;                                     // [Nq][D]  (+ row Nq: f_s)
-    float* whS = fwS + (Nq + 1) * D;                          // [Nq][dl]
-    float* kbS = whS + Nq * dl;                               // [Nq][dl]
-    for (int idx = t * 4; idx < Nq * D; idx += 1024) stg4(fwS + idx, ldg4(fw + (size_t)b * Nq * D + idx));
-    for (int idx = t * 4; idx < D; idx += 1024) stg4(fwS + Nq * D + idx, ldg4(fs + (size_t)b * D + idx));
+    float* fwS = wp_smem;                                     // [nr][D]  (+ one row: f_s)
+    float* whS = fwS + (rpp + 1) * D;                         // [nr][dl]
+    float* kbS = whS + rpp * dl;                              // [nr][dl]
+    for (int idx = t * 4; idx < nr * D; idx += 1024) stg4(fwS + idx, ldg4(fw + ((size_t)b * Nq + r0) * D + idx));
+    for (int idx = t * 4; idx < D; idx += 1024) stg4(fwS + rpp * D + idx, ldg4(fs + (size_t)b * D + idx));
     __syncthreads();
-    const size_t ob = ((size_t)k * B + b) * Nq * dl;
-    rows_matT(fwS, D, Nq, WH, dl, D, [&](int w, int e, float v) {
-        v = (v + bWH[e]) * qmask[(size_t)b * Nq + w];
+    const size_t ob = (((size_t)k * B + b) * Nq + r0) * dl;
+    rows_matT(fwS, D, nr, WH, dl, D, [&](int w, int e, float v) {
+        v = (v + bWH[e]) * qmask[(size_t)b * Nq + r0 + w];
         whS[w * dl + e] = v; what[ob + (size_t)w * dl + e] = v;
     });
-    rows_matT(fwS + Nq * D, D, 1, SH, dl, D, [&](int, int e, float v) { shat[((size_t)k * B + b) * dl + e] = v + bSH[e]; });
+    if (blockIdx.z == 0) rows_matT(fwS + rpp * D, D, 1, SH, dl, D, [&](int, int e, float v) { shat[((size_t)k * B + b) * dl + e] = v + bSH[e]; });
     __syncthreads();
-    rows_matT(whS, dl, Nq, AK, dl, dl, [&](int w, int e, float v) {
+    rows_matT(whS, dl, nr, AK, dl, dl, [&](int w, int e, float v) {
         v += bAK[e];
         kbS[w * dl + e] = v; kb[ob + (size_t)w * dl + e] = v;
     });
     __syncthreads();
-    rows_mat(kbS, dl, Nq, AQ, dl, dl, [&](int w, int d, float v) { Mq[ob + (size_t)w * dl + d] = v; });
-    if (t < Nq) {
+    rows_mat(kbS, dl, nr, AQ, dl, dl, [&](int w, int d, float v) { Mq[ob + (size_t)w * dl + d] = v; });
+    if (t < nr) {
         float s = 0.f;
         for (int e = 0; e < dl; ++e) s = fmaf(kbS[t * dl + e], bAQ[e], s);
-        uq[((size_t)k * B + b) * Nq + t] = s;
+        uq[((size_t)k * B + b) * Nq + r0 + t] = s;
     }
 }
 
@@ -109,62 +113,65 @@ __host__ __device__ inline size_t wp_slab_floats(int D, int dl) { return (size_t
 
 __global__ __launch_bounds__(256)
 void word_prep_bwd_kernel(WordOuts G, const float* __restrict__ fw, const float* __restrict__ fs, const float* __restrict__ qmask,
-                          const float* __restrict__ what, const float* __restrict__ kb, WordParams P, int B, int Nq, int D, int dl,
+                          const float* __restrict__ what, const float* __restrict__ kb, WordParams P, int B, int Nq, int D, int dl, int rpp,
                           float* __restrict__ dfw_part, float* __restrict__ dfs_part, float* __restrict__ slab)
 {
     extern __shared__ __attribute__((aligned(16))) float wp_smem[];
     const int b = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+    const int r0 = blockIdx.z * rpp, Nw = min(Nq, r0 + rpp) - r0;       // this part's words r0 .. r0 + Nw
+    if (Nw <= 0) return;
     const float *WH = P.p[8 * k], *SH = P.p[8 * k + 2], *AK = P.p[8 * k + 4], *AQ = P.p[8 * k + 6], *bAQ = P.p[8 * k + 7];
-    const int nd = Nq * dl;
-    float* fwS = wp_smem;                                     // [Nq][D]
-    float* dMqS = fwS + Nq * D;                               // [Nq][dl]
-    float* kbS = dMqS + nd;
-    float* whS = kbS + nd;
-    float* dkbS = whS + nd;
-    float* dpreS = dkbS + nd;
-    float* duS = dpreS + nd;                                  // [Nq] duq, then [dl] dshat
+    const int nd = Nw * dl, ndp = rpp * dl;
+    float* fwS = wp_smem;                                     // [Nw][D]
+    float* dMqS = fwS + rpp * D;                              // [Nw][dl]
+    float* kbS = dMqS + ndp;
+    float* whS = kbS + ndp;
+    float* dkbS = whS + ndp;
+    float* dpreS = dkbS + ndp;
+    float* duS = dpreS + ndp;                                 // [32] duq, then [dl] dshat
     float* dshS = duS + 32;
-    const size_t ob = ((size_t)k * B + b) * nd;
+    const size_t ob = (((size_t)k * B + b) * Nq + r0) * dl, ogb = ((size_t)b * Nq + r0) * dl;
     const float* dMq = G.dMq[k]; const float* duq = G.duq[k]; const float* dwh = G.dwhat[k]; const float* dsh = G.dshat[k];
-    for (int idx = t * 4; idx < Nq * D; idx += 1024) stg4(fwS + idx, ldg4(fw + (size_t)b * Nq * D + idx));
+    for (int idx = t * 4; idx < Nw * D; idx += 1024) stg4(fwS + idx, ldg4(fw + ((size_t)b * Nq + r0) * D + idx));
     for (int idx = t * 4; idx < nd; idx += 1024) {
-        stg4(dMqS + idx, dMq ? ldg4(dMq + (size_t)b * nd + idx) : f4zero());
+        stg4(dMqS + idx, dMq ? ldg4(dMq + ogb + idx) : f4zero());
         stg4(kbS + idx, ldg4(kb + ob + idx));
         stg4(whS + idx, ldg4(what + ob + idx));
     }
-    if (t < 32) duS[t] = (duq && t < Nq) ? duq[(size_t)b * Nq + t] : 0.f;
+    if (t < 32) duS[t] = (duq && t < Nw) ? duq[(size_t)b * Nq + r0 + t] : 0.f;
     for (int e = t; e < dl; e += 256) dshS[e] = dsh ? dsh[(size_t)b * dl + e] : 0.f;
     __syncthreads();
     // dkb = dMq AQ^T + duq (x) bAQ
-    rows_matT(dMqS, dl, Nq, AQ, dl, dl, [&](int w, int e, float v) { dkbS[w * dl + e] = fmaf(duS[w], bAQ[e], v); });
+    rows_matT(dMqS, dl, Nw, AQ, dl, dl, [&](int w, int e, float v) { dkbS[w * dl + e] = fmaf(duS[w], bAQ[e], v); });
     __syncthreads();
     // dwhat = dwhat_ext + dkb AK ; dpre = dwhat * qmask
-    rows_mat(dkbS, dl, Nq, AK, dl, dl, [&](int w, int c, float v) {
-        if (dwh) v += dwh[(size_t)b * nd + w * dl + c];
-        dpreS[w * dl + c] = v * qmask[(size_t)b * Nq + w];
+    rows_mat(dkbS, dl, Nw, AK, dl, dl, [&](int w, int c, float v) {
+        if (dwh) v += dwh[ogb + w * dl + c];
+        dpreS[w * dl + c] = v * qmask[(size_t)b * Nq + r0 + w];
     });
     __syncthreads();
     // row-side gradients of this layer: dfw = dpre WH, dfs = dshat SH
-    rows_mat(dpreS, dl, Nq, WH, dl, D, [&](int w, int d, float v) { dfw_part[(((size_t)k * B + b) * Nq + w) * D + d] = v; });
-    rows_mat(dshS, dl, 1, SH, dl, D, [&](int, int d, float v) { dfs_part[((size_t)k * B + b) * D + d] = v; });
-    // per-sample partial weight gradients
-    float* sl = slab + ((size_t)k * B + b) * wp_slab_floats(D, dl);
+    rows_mat(dpreS, dl, Nw, WH, dl, D, [&](int w, int d, float v) { dfw_part[(((size_t)k * B + b) * Nq + r0 + w) * D + d] = v; });
+    if (blockIdx.z == 0) rows_mat(dshS, dl, 1, SH, dl, D, [&](int, int d, float v) { dfs_part[((size_t)k * B + b) * D + d] = v; });
+    // partial weight gradients of this (sample, part)
+    const int Nq_ = Nw;                                       // the sums below run over this part's words
+    float* sl = slab + (((size_t)k * B + b) * gridDim.z + blockIdx.z) * wp_slab_floats(D, dl);
     float* sAQ = sl; float* sbAQ = sAQ + dl * dl; float* sAK = sbAQ + dl; float* sbAK = sAK + dl * dl; float* sWH = sbAK + dl; float* sbWH = sWH + (size_t)dl * D;
     for (int idx = t; idx < dl * dl; idx += 256) {
         const int e = idx / dl, c = idx % dl;
         float a = 0.f, a2 = 0.f;
-        for (int w = 0; w < Nq; ++w) { a = fmaf(kbS[w * dl + e], dMqS[w * dl + c], a); a2 = fmaf(dkbS[w * dl + e], whS[w * dl + c], a2); }
+        for (int w = 0; w < Nq_; ++w) { a = fmaf(kbS[w * dl + e], dMqS[w * dl + c], a); a2 = fmaf(dkbS[w * dl + e], whS[w * dl + c], a2); }
         sAQ[idx] = a; sAK[idx] = a2;
     }
     for (int e = t; e < dl; e += 256) {
         float a = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int w = 0; w < Nq; ++w) { a = fmaf(kbS[w * dl + e], duS[w], a); a2 += dkbS[w * dl + e]; a3 += dpreS[w * dl + e]; }
+        for (int w = 0; w < Nq_; ++w) { a = fmaf(kbS[w * dl + e], duS[w], a); a2 += dkbS[w * dl + e]; a3 += dpreS[w * dl + e]; }
         sbAQ[e] = a; sbAK[e] = a2; sbWH[e] = a3;
     }
     for (int idx = t * 4; idx < dl * D; idx += 1024) {
         const int e = idx / D, d = idx % D;
         float4 a = f4zero();
-        for (int w = 0; w < Nq; ++w) a = f4fma(ldg4(fwS + w * D + d), dpreS[w * dl + e], a);
+        for (int w = 0; w < Nq_; ++w) a = f4fma(ldg4(fwS + w * D + d), dpreS[w * dl + e], a);
         stg4(sWH + idx, a);
     }
 }
@@ -172,7 +179,8 @@ void word_prep_bwd_kernel(WordOuts G, const float* __restrict__ fw, const float*
 // sums over the batch in sample order; grid (chunks, nl [+1 for the row-side sums])
 __global__ __launch_bounds__(256)
 void word_prep_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dfw_part, const float* __restrict__ dfs_part, WordOuts G,
-                             const float* __restrict__ fs, WordGrads Q, int nl, int B, int Nq, int D, int dl, float* __restrict__ dfw, float* __restrict__ dfs)
+                             const float* __restrict__ fs, WordGrads Q, int nl, int B, int Nq, int D, int dl, int parts, float* __restrict__ dfw,
+                             float* __restrict__ dfs)
 {
     const int k = blockIdx.y;
     const size_t x = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -186,9 +194,9 @@ void word_prep_reduce_kernel(const float* __restrict__ slab, const float* __rest
     float* dWH = Q.p[8 * k]; float* dbWH = Q.p[8 * k + 1]; float* dSH = Q.p[8 * k + 2]; float* dbSH = Q.p[8 * k + 3]; float* dAK = Q.p[8 * k + 4];
     float* dbAK = Q.p[8 * k + 5]; float* dAQ = Q.p[8 * k + 6]; float* dbAQ = Q.p[8 * k + 7];
     if (x < ss) {
-        const float* p = slab + (size_t)k * B * ss + x;
+        const float* p = slab + (size_t)k * B * parts * ss + x;
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += p[(size_t)b * ss];
+        for (int b = 0; b < B * parts; ++b) s += p[(size_t)b * ss];
         const size_t o1 = (size_t)dl * dl, o2 = o1 + dl, o3 = o2 + o1, o4 = o3 + dl, o5 = o4 + (size_t)dl * D;
         if (x < o1) dAQ[x] = s; else if (x < o2) dbAQ[x - o1] = s; else if (x < o3) dAK[x - o2] = s; else if (x < o4) dbAK[x - o3] = s;
         else if (x < o5) dWH[x - o4] = s; else dbWH[x - o5] = s;
@@ -211,31 +219,41 @@ void word_prep_reduce_kernel(const float* __restrict__ slab, const float* __rest
 
 using namespace smin;
 
-static size_t wp_fwd_lds(int Nq, int D, int dl) { return sizeof(float) * ((size_t)(Nq + 1) * D + 2 * (size_t)Nq * dl); }
-static size_t wp_bwd_lds(int Nq, int D, int dl) { return sizeof(float) * ((size_t)Nq * D + 5 * (size_t)Nq * dl + 32 + dl); }
+static size_t wp_fwd_lds(int rpp, int D, int dl) { return sizeof(float) * ((size_t)(rpp + 1) * D + 2 * (size_t)rpp * dl); }
+static size_t wp_bwd_lds(int rpp, int D, int dl) { return sizeof(float) * ((size_t)rpp * D + 5 * (size_t)rpp * dl + 32 + dl); }
+// rows per part: enough (sample, layer, part) workgroups to fill the chip, at least one word each
+static int wp_rows_per_part(int nl, int B, int Nq)
+{
+    int parts = cdiv(384, nl * B);
+    if (parts > Nq) parts = Nq;
+    if (parts < 1) parts = 1;
+    return cdiv(Nq, parts);
+}
 
 extern "C" int smin_word_prep_fwd(void* stream, const float* fw, const float* fs, const float* qmask, const float* const* params, int nl, int B, int Nq, int D,
                                   int dl, float* what, float* shat, float* kb, float* Mq, float* uq)
 {
-    SMIN_REQUIRE(nl >= 1 && nl <= WP_MAXL && Nq >= 1 && Nq <= 32 && D % 4 == 0 && dl % 4 == 0 && dl <= 128 && wp_fwd_lds(Nq, D, dl) <= 160 * 1024);
     if (B == 0) return 0;
+    const int rpp = wp_rows_per_part(nl, B, Nq), parts = cdiv(Nq, rpp);
+    SMIN_REQUIRE(nl >= 1 && nl <= WP_MAXL && Nq >= 1 && Nq <= 32 && D % 4 == 0 && dl % 4 == 0 && dl <= 128 && wp_fwd_lds(rpp, D, dl) <= 160 * 1024);
     WordParams P;
     for (int i = 0; i < WP_MAXL * 8; ++i) P.p[i] = params[i < nl * 8 ? i : 0];
-    const size_t lds = wp_fwd_lds(Nq, D, dl);
+    const size_t lds = wp_fwd_lds(rpp, D, dl);
     static size_t lds_set = 0;
     if (lds > 64 * 1024 && lds > lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&word_prep_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(word_prep_fwd_kernel, dim3(B, nl), dim3(256), lds, (hipStream_t)stream, fw, fs, qmask, P, B, Nq, D, dl, what, shat, kb, Mq, uq);
+    hipLaunchKernelGGL(word_prep_fwd_kernel, dim3(B, nl, parts), dim3(256), lds, (hipStream_t)stream, fw, fs, qmask, P, B, Nq, D, dl, rpp, what, shat, kb, Mq, uq);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" size_t smin_word_prep_bwd_workspace_bytes(int nl, int B, int Nq, int D, int dl)
 {
-    return sizeof(float) * ((size_t)nl * B * wp_slab_floats(D, dl) + (size_t)nl * B * Nq * D + (size_t)nl * B * D + 64);
+    const int parts = B > 0 ? cdiv(Nq, wp_rows_per_part(nl, B, Nq)) : 1;
+    return sizeof(float) * ((size_t)nl * B * parts * wp_slab_floats(D, dl) + (size_t)nl * B * Nq * D + (size_t)nl * B * D + 64);
 }
 
 extern "C" int smin_word_prep_bwd(void* stream, const float* const* dwhat, const float* const* dshat, const float* const* dMq, const float* const* duq,
@@ -243,29 +261,30 @@ extern "C" int smin_word_prep_bwd(void* stream, const float* const* dwhat, const
                                   int nl, int B, int Nq, int D, int dl, float* dfw, float* dfs, float* const* dparams, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
-    SMIN_REQUIRE(nl >= 1 && nl <= WP_MAXL && Nq >= 1 && Nq <= 32 && D % 4 == 0 && dl % 4 == 0 && dl <= 128 && wp_bwd_lds(Nq, D, dl) <= 160 * 1024);
-    SMIN_REQUIRE(ws_bytes >= smin_word_prep_bwd_workspace_bytes(nl, B, Nq, D, dl));
     if (B == 0) return 0;
+    const int rpp = wp_rows_per_part(nl, B, Nq), parts = cdiv(Nq, rpp);
+    SMIN_REQUIRE(nl >= 1 && nl <= WP_MAXL && Nq >= 1 && Nq <= 32 && D % 4 == 0 && dl % 4 == 0 && dl <= 128 && wp_bwd_lds(rpp, D, dl) <= 160 * 1024);
+    SMIN_REQUIRE(ws_bytes >= smin_word_prep_bwd_workspace_bytes(nl, B, Nq, D, dl));
     WordParams P; WordGrads Q; WordOuts G;
     for (int i = 0; i < WP_MAXL * 8; ++i) { P.p[i] = params[i < nl * 8 ? i : 0]; Q.p[i] = dparams[i < nl * 8 ? i : 0]; }
     for (int k = 0; k < WP_MAXL; ++k) {
         G.dwhat[k] = k < nl ? dwhat[k] : nullptr; G.dshat[k] = k < nl ? dshat[k] : nullptr; G.dMq[k] = k < nl ? dMq[k] : nullptr; G.duq[k] = k < nl ? duq[k] : nullptr;
     }
     float* slab = reinterpret_cast<float*>(ws);
-    float* dfw_part = slab + (size_t)nl * B * wp_slab_floats(D, dl);
+    float* dfw_part = slab + (size_t)nl * B * parts * wp_slab_floats(D, dl);
     float* dfs_part = dfw_part + (size_t)nl * B * Nq * D;
-    const size_t lds = wp_bwd_lds(Nq, D, dl);
+    const size_t lds = wp_bwd_lds(rpp, D, dl);
     static size_t lds_set = 0;
     if (lds > 64 * 1024 && lds > lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&word_prep_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(word_prep_bwd_kernel, dim3(B, nl), dim3(256), lds, st, G, fw, fs, qmask, what, kb, P, B, Nq, D, dl, dfw_part, dfs_part, slab);
+    hipLaunchKernelGGL(word_prep_bwd_kernel, dim3(B, nl, parts), dim3(256), lds, st, G, fw, fs, qmask, what, kb, P, B, Nq, D, dl, rpp, dfw_part, dfs_part, slab);
     SMIN_LAUNCH_CHECK();
     const size_t per_layer = wp_slab_floats(D, dl) + (size_t)dl * D + dl, rows = (size_t)B * Nq * D + (size_t)B * D;
     const size_t mx = per_layer > rows ? per_layer : rows;
-    hipLaunchKernelGGL(word_prep_reduce_kernel, dim3((unsigned)((mx + 255) / 256), nl + 1), dim3(256), 0, st, slab, dfw_part, dfs_part, G, fs, Q, nl, B, Nq, D, dl,
+    hipLaunchKernelGGL(word_prep_reduce_kernel, dim3((unsigned)((mx + 255) / 256), nl + 1), dim3(256), 0, st, slab, dfw_part, dfs_part, G, fs, Q, nl, B, Nq, D, dl, parts,
                        dfw, dfs);
     SMIN_LAUNCH_CHECK();
     return 0;
