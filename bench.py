@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only")
-    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the dense NT contractions")
+    ap.add_argument("--gemm", "--dtype", dest="gemm", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the dense contractions (f32 = the reference's, the headline; bf16 = BASELINE.json configs[1])")
     ap.add_argument("--feed", default="resident", choices=["resident", "host"],
                     help="resident (default, the headline): inputs live in HBM; host: every step's batch comes through BatchFeeder "
                          "(pinned host buffers -> async H2D on a copy stream -> masks/targets built on the device), the PCIe-inclusive rate")
@@ -261,6 +262,10 @@ def main():
                     "frac": g["frac"], "traffic": pmc.get("moment_fwd", {}).get("hbm_bytes_per_launch"), "avg_launch_ms": g["avg_launch_ms"],
                     "launches_timed": g["launches_timed"], "flops_per_launch": mu_flops, "valid_cells_per_launch": n_valid,
                     "algorithmic_bytes_per_launch": 4.0 * n_valid * 4 * D}
+        if args.gemm == "bf16":                                # bf16 products run at 16x the fp32 matrix rate: the contraction is bound by its operand traffic
+            ach = roofline["algorithmic_bytes_per_launch"] / (g["avg_launch_ms"] * 1e-3) / 1e9
+            roofline.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                             "tflops": g["achieved"]})
         for k in ("moment_dx", "moment_dw"):
             if gemms[k]:
                 gemms[k]["traffic"] = pmc.get(k, {}).get("hbm_bytes_per_launch")
@@ -283,7 +288,8 @@ def main():
                             "frac_mfma": per_rank_valid * fa / t_fb / 1e12 / PEAK_F32_MFMA_TFLOPS,
                             "frac_mfma_executed": per_rank_valid * fe / t_fb / 1e12 / PEAK_F32_MFMA_TFLOPS,
                             "frac_hbm": per_rank_valid * ba / t_fb / 1e9 / PEAK_HBM_GBS,
-                            "bound": "mfma (fp32: ~110 FLOP/B is above the 20 FLOP/B ridge)"}
+                            "bound": "mfma (fp32: ~110 FLOP/B is above the 20 FLOP/B ridge)" if args.gemm != "bf16"
+                                     else "hbm (bf16 products: the 312 FLOP/B ridge is above the path's ~110 FLOP/B)"}
 
     if rank == 0:
         total_B = B * world
@@ -296,7 +302,8 @@ def main():
             "metric": "proposals/sec (fwd+bwd)", "value": total_B * L * L / (elapsed / args.steps), "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_with_adam": None if args.no_optimizer else ms,
             "ms_fwd_bwd": elapsed_fb / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 products, fp32 accumulate)", "bf16": "bf16 (products; fp32 accumulate and storage)"}[args.gemm],
             "data": "synthetic" if args.feed == "resident" else "synthetic, fed from pinned host memory every step (BatchFeeder: async H2D + device-side targets)",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"

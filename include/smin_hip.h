@@ -38,6 +38,8 @@ int smin_abi_version(void);
  *   0 (default) exact fp32 on v_mfma_f32_32x32x2_f32;
  *   1 split-bf16: operands split into hi+lo bf16 on the fly, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with
  *     fp32 accumulation (~1e-5 relative on a dot product, 5.3x the fp32 matrix rate).
+ *   2 plain bf16: every contraction (forward, input gradients AND weight gradients) rounds its operands to bf16 once and
+ *     accumulates in fp32 on v_mfma_f32_32x32x16_bf16 (~4e-3 relative per product; BASELINE.json configs[1]).
  * Process-wide; returns 0 or -1 for an unknown mode. */
 int smin_set_gemm_mode(int mode);
 int smin_get_gemm_mode(void);

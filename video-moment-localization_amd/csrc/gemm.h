@@ -315,7 +315,10 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool MINI, bool KFULL, class AM, class BM_, class EP>
+// NPROD = 3: the split form above.  NPROD = 1: plain bf16 -- operands rounded to bf16 once, one product per block, fp32
+// accumulate ("bf16" mode of smin_set_gemm_mode: ~4e-3 relative per product, 16x the fp32 matrix rate; the contraction is
+// then bound by its fp32 operand traffic, not by the matrix pipe).
+template <int NPROD, bool MINI, bool KFULL, class AM, class BM_, class EP>
 __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const BM_& bm, const EP& ep, int M, int N, int K,
                                                 int row_base, int col_base)
 {
@@ -368,10 +371,10 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
             const int o = (lr + RPP * p) * RS + kq;
             split_bf16x4(st.a[p], hi, lo);
             *reinterpret_cast<uint2*>(base + o) = hi;
-            *reinterpret_cast<uint2*>(base + IMG + o) = lo;
+            if (NPROD == 3) *reinterpret_cast<uint2*>(base + IMG + o) = lo;
             split_bf16x4(st.b[p], hi, lo);
             *reinterpret_cast<uint2*>(base + 2 * IMG + o) = hi;
-            *reinterpret_cast<uint2*>(base + 3 * IMG + o) = lo;
+            if (NPROD == 3) *reinterpret_cast<uint2*>(base + 3 * IMG + o) = lo;
         }
     };
     auto compute = [&](int cur) {
@@ -382,16 +385,20 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
 #pragma unroll
         for (int i = 0; i < NMI; ++i) {
             ah[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * RS);
-            al[i] = *reinterpret_cast<const bf16x8*>(ab + IMG + i * 32 * RS);
             bh[i] = *reinterpret_cast<const bf16x8*>(bb + i * 32 * RS);
-            bl[i] = *reinterpret_cast<const bf16x8*>(bb + IMG + i * 32 * RS);
+            if (NPROD == 3) {
+                al[i] = *reinterpret_cast<const bf16x8*>(ab + IMG + i * 32 * RS);
+                bl[i] = *reinterpret_cast<const bf16x8*>(bb + IMG + i * 32 * RS);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NMI; ++i)
 #pragma unroll
             for (int j = 0; j < NMI; ++j) {
-                acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
-                acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+                if (NPROD == 3) {
+                    acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+                }
                 acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
             }
     };
@@ -429,7 +436,7 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
     }
 }
 
-template <bool KFULL, class AM, class BM_, class EP>
+template <int NPROD, bool KFULL, class AM, class BM_, class EP>
 __global__ __launch_bounds__(256, 3)
 void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m, int tiles_n, int main_blocks)
 {
@@ -438,14 +445,15 @@ void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
         if (tm >= main_tiles_m) return;
-        gemm_nt_x3_body<false, KFULL>(smem, am, bm, ep, M, N, K, tm * 128, tn * 128);
+        gemm_nt_x3_body<NPROD, false, KFULL>(smem, am, bm, ep, M, N, K, tm * 128, tn * 128);
     } else {
         const int id = blockIdx.x - main_blocks;
-        gemm_nt_x3_body<true, KFULL>(smem, am, bm, ep, M, N, K, main_tiles_m * 128 + (id / tiles_n) * 32, (id % tiles_n) * 128);
+        gemm_nt_x3_body<NPROD, true, KFULL>(smem, am, bm, ep, M, N, K, main_tiles_m * 128 + (id / tiles_n) * 32, (id % tiles_n) * 128);
     }
 }
 
-// 0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3) for the NT contractions; set by smin_set_gemm_mode()
+// 0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3) for the NT contractions, 2 = plain bf16 products with fp32
+// accumulation for every contraction (NT and TN); set by smin_set_gemm_mode()
 extern int g_gemm_mode;
 
 constexpr int GEMM_SLOTS = 768;         // resident workgroups: 256 CUs x 3 (40 KB LDS, <= 168 VGPRs each)
@@ -467,10 +475,17 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
     const int main_blocks = cdiv(main_tiles_m, 8) * 8 * tiles_n;
     if (g_gemm_mode == 1) {
         if (K % 16 == 0)
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<3, true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
                                main_tiles_m, tiles_n, main_blocks);
         else
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<3, false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                               main_tiles_m, tiles_n, main_blocks);
+    } else if (g_gemm_mode == 2) {
+        if (K % 16 == 0)
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<1, true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
+                               main_tiles_m, tiles_n, main_blocks);
+        else
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<1, false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
                                main_tiles_m, tiles_n, main_blocks);
     } else if (K % 16 == 0)
         hipLaunchKernelGGL((gemm_nt_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
@@ -605,6 +620,117 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
     if (BIAS && tj == 0 && t < BI && ti * BI + t < I) bias_slab[(size_t)z * I + ti * BI + t] = bsum;
 }
 
+
+// ------------------------------------------------------------------ TN kernel, plain bf16 products ("bf16" mode)
+// Same tiling, splits and XCD-aware order as gemm_tn_kernel; the row (contraction) index is the MFMA k index, so the tiles are
+// kept in LDS transposed ([column][32 rows] in bf16, two consecutive rows packed per 32-bit store) and each lane reads its
+// eight consecutive rows with one 16-byte load.  fp32 accumulation; the bias column sums add the bf16-rounded values.
+template <class AM, class BM_, bool BIAS>
+__global__ __launch_bounds__(256, 3)
+void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__ bias_slab,
+                         int Mrows, int I, int J, int rows_per_split, int tiles_i, int tiles_j, int splits)
+{
+    constexpr int BI = 128, BJ = 128, BK = 32, RS = BK + 8;          // row stride 40 bf16 = 80 B
+    __shared__ __attribute__((aligned(16))) unsigned short tsm[2 * (BI + BJ) * RS];       // 40,960 B
+    unsigned short* As = tsm;
+    unsigned short* Bs = tsm + 2 * BI * RS;
+    const int tiles = tiles_i * tiles_j;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int z = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (z >= splits) return;
+    const int ti = tile % tiles_i, tj = tile / tiles_i;
+    const int m_begin = z * rows_per_split;
+    const int m_end = min(Mrows, m_begin + rows_per_split);
+    const int t = threadIdx.x, lk = t >> 5, c4 = (t & 31) * 4;          // thread: rows 2lk, 2lk+1 (+16), columns c4 .. c4+3
+    const int ia = min(ti * BI + c4, I - 4), jb = min(tj * BJ + c4, J - 4);
+    const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+    const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
+    struct Stage { float4 a[4], b[4]; };
+    auto g_load = [&](Stage& st, int kt) {
+        const int m0 = m_begin + min(kt, max(nk - 1, 0)) * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + 2 * lk + (p & 1) + 16 * (p >> 1);
+            const bool ok = m < m_end;
+            const int mc = min(m, Mrows - 1);
+            st.a[p] = f4sel(ok, am.at(am.row(mc), ia));
+            st.b[p] = f4sel(ok, bm.at(bm.row(mc), jb));
+        }
+    };
+    auto pack2 = [](float x, float y) {
+        return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
+    };
+    auto s_store = [&](const Stage& st, int buf) {
+        unsigned short* a0 = As + buf * BI * RS + 2 * lk;
+        unsigned short* b0 = Bs + buf * BJ * RS + 2 * lk;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                             // rows (2lk, 2lk+1) + 16*pp
+            const float4 x0 = st.a[2 * pp], x1 = st.a[2 * pp + 1], y0 = st.b[2 * pp], y1 = st.b[2 * pp + 1];
+            *reinterpret_cast<unsigned*>(a0 + (c4 + 0) * RS + 16 * pp) = pack2(x0.x, x1.x);
+            *reinterpret_cast<unsigned*>(a0 + (c4 + 1) * RS + 16 * pp) = pack2(x0.y, x1.y);
+            *reinterpret_cast<unsigned*>(a0 + (c4 + 2) * RS + 16 * pp) = pack2(x0.z, x1.z);
+            *reinterpret_cast<unsigned*>(a0 + (c4 + 3) * RS + 16 * pp) = pack2(x0.w, x1.w);
+            *reinterpret_cast<unsigned*>(b0 + (c4 + 0) * RS + 16 * pp) = pack2(y0.x, y1.x);
+            *reinterpret_cast<unsigned*>(b0 + (c4 + 1) * RS + 16 * pp) = pack2(y0.y, y1.y);
+            *reinterpret_cast<unsigned*>(b0 + (c4 + 2) * RS + 16 * pp) = pack2(y0.z, y1.z);
+            *reinterpret_cast<unsigned*>(b0 + (c4 + 3) * RS + 16 * pp) = pack2(y0.w, y1.w);
+        }
+    };
+    auto compute = [&](int cur) {
+        const unsigned short* ab = As + cur * BI * RS + (wm * 64 + l31) * RS + 8 * h;
+        const unsigned short* bb = Bs + cur * BJ * RS + (wn * 64 + l31) * RS + 8 * h;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + 16 * s), a1 = *reinterpret_cast<const bf16x8*>(ab + 32 * RS + 16 * s);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bb + 16 * s), b1 = *reinterpret_cast<const bf16x8*>(bb + 32 * RS + 16 * s);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
+        if (BIAS && tj == 0 && t < BI) {
+            const unsigned short* col = As + cur * BI * RS + t * RS;
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) bsum += (float)__builtin_bit_cast(__bf16, col[kk]);
+        }
+    };
+    Stage s0, s1;
+    if (nk > 0) { g_load(s0, 0); s_store(s0, 0); g_load(s0, 1); g_load(s1, 2); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) s_store(s0, 1);
+        g_load(s0, kt + 3);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) s_store(s1, 0);
+            g_load(s1, kt + 4);
+            __syncthreads();
+        }
+    }
+    float* out = slab + (size_t)z * I * J;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ti * BI + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int j = tj * BJ + wn * 64 + ni * 32 + l31;
+                if (i < I && j < J) out[(size_t)i * J + j] = acc[mi][ni][r];
+            }
+    if (BIAS && tj == 0 && t < BI && ti * BI + t < I) bias_slab[(size_t)z * I + ti * BI + t] = bsum;
+}
+
 // number of m-splits so that the grid fills the chip (>= ~2 workgroups per CU)
 static inline int tn_splits(int Mrows, int I, int J)
 {
@@ -624,6 +750,16 @@ static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, fl
     const int rows_per_split = cdiv(cdiv(Mrows, splits), 32) * 32;
     const int tiles_i = cdiv(I, 128), tiles_j = cdiv(J, 128);
     dim3 grid(cdiv(splits, 8) * 8 * tiles_i * tiles_j);
+    if (g_gemm_mode == 2) {
+        if (bias_slab)
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+                               tiles_i, tiles_j, splits);
+        else
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+                               tiles_i, tiles_j, splits);
+        SMIN_LAUNCH_CHECK();
+        return 0;
+    }
     if (bias_slab)
         hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
                            tiles_i, tiles_j, splits);
