@@ -250,11 +250,6 @@ def main():
             pmc = json.load(open(pmc_path))
         except Exception:
             pmc = {}
-    elif args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
-        try:                                                # round-1 file: forward contraction only
-            pmc = {"moment_fwd": json.load(open(os.path.join(ROOT, "profiles", "pmc_moment_fwd.json")))}
-        except Exception:
-            pmc = {}
     roofline = None
     if gemms["moment_fwd"]:
         g = gemms["moment_fwd"]
@@ -317,7 +312,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

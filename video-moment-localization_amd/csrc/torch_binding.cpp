@@ -666,8 +666,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
         for (int64_t k = 0; k < nl; ++k) wch.push_back(lp(k, L_CH_W));
         Wch_all = at::cat(wch);
         const_all = consts[0];
+        // a layer's word-side operands in one launch.  One node per layer, not one for all: a layer's backward then runs as soon
+        // as that layer's attention gradients exist instead of after the whole backward pass (where it delayed the query encoder)
         {
-            std::vector<Tensor> wp;                               // every layer's word-side operands in one launch
+            // every layer's word-side operands in one launch (one autograd node: its backward then runs at the tail of the backward
+            // pass; one node per layer measured 1.4 ms/step slower -- the three backward launches then run on the second stream
+            // beside the layers' matrix kernels and take CUs from the critical path)
+            std::vector<Tensor> wp;
             for (int64_t k = 0; k < nl; ++k)
                 for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) wp.push_back(lp(k, which));
             auto wo = WordPrep::apply(fw, fs, qmf, at::TensorList(wp));

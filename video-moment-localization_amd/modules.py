@@ -446,7 +446,9 @@ class SMIN(nn.Module):
             # layer 0's constant rides on the clip means; later layers get theirs in the contraction that forms chat_k,
             # whose weight-gradient pass yields the constant's gradient (a column sum) for free
             const_all = consts[0]
-            qmr = _rows(query_mask)                                       # every layer's word-side operands in one launch
+            # every layer's word-side operands in one launch (one node: its backward runs at the tail of the backward pass; a node
+            # per layer measured 1.4 ms/step slower, its backward launches take CUs from the layers' matrix kernels)
+            qmr = _rows(query_mask)
             wo = WordPrepFn.apply(fw, fs, qmr, *[p for cu in cus for p in cu.word_params()])
             words = [(wo[4 * k + 2], wo[4 * k + 3], wo[4 * k], wo[4 * k + 1], qmr) for k in range(nl)]
             Pcats = [[torch.cat([torch.matmul(cus[k].linear_c_hat.weight, cus[l].linear_c.weight) for l in range(lo, min(lo + 4, k))], dim=1)
