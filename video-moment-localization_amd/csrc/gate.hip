@@ -45,22 +45,32 @@ void gate_bwd_kernel(GradList dh, GradList dres, const float* __restrict__ fm, c
     for (int d = threadIdx.x * 4; d < D; d += 512) {
         const float4 s4 = ldg4(fs + (size_t)b * D + d);
         float4 acc = f4zero();
-        for (int n = n_begin; n < n_end; ++n) {
-            const size_t off = (size_t)n * D + d;
-            const float4 ds = grad_sum(dh, off);                    // every consumer of hbar (summed here, not by autograd)
-            const float4 x = ldg4(fm + off);
-            float4 o;
-#define GATE1(F)                                                                  \
-            {                                                                     \
-                const float g = 1.0f / (1.0f + expf(-x.F * s4.F));                \
-                const float gg = g * (1.0f - g);                                  \
-                o.F = ds.F * (g + x.F * gg * s4.F);                               \
-                acc.F = fmaf(ds.F, x.F * x.F * gg, acc.F);                        \
+        // four cells per trip: all their loads (up to eight gradient tensors + fm each) are requested before the first is used --
+        // one cell per trip left a thread with one HBM round trip per cell (4.1 TB/s on 1.2 GB)
+        for (int n0 = n_begin; n0 < n_end; n0 += 4) {
+            float4 ds[4], x[4], dr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t off = (size_t)min(n0 + u, n_end - 1) * D + d;
+                ds[u] = grad_sum(dh, off);                          // every consumer of hbar (summed here, not by autograd)
+                x[u] = ldg4(fm + off);
+                dr[u] = dres.n > 0 ? grad_sum(dres, off) : f4zero();   // gradients of the pass-through copies of f_m
             }
-            GATE1(x) GATE1(y) GATE1(z) GATE1(w)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (n0 + u >= n_end) break;
+                float4 o;
+#define GATE1(F)                                                                  \
+                {                                                                 \
+                    const float g = 1.0f / (1.0f + expf(-x[u].F * s4.F));         \
+                    const float gg = g * (1.0f - g);                              \
+                    o.F = ds[u].F * (g + x[u].F * gg * s4.F);                     \
+                    acc.F = fmaf(ds[u].F, x[u].F * x[u].F * gg, acc.F);           \
+                }
+                GATE1(x) GATE1(y) GATE1(z) GATE1(w)
 #undef GATE1
-            if (dres.n > 0) o = f4add(o, grad_sum(dres, off));      // gradients of the pass-through copies of f_m
-            stg4(dfm + off, o);
+                stg4(dfm + (size_t)(n0 + u) * D + d, f4add(o, dr[u]));
+            }
         }
         stg4(partial + ((size_t)b * max_chunks + chunk) * D + d, acc);
     }
