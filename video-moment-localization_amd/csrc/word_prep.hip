@@ -35,7 +35,25 @@ __device__ __forceinline__ void rows_matT(const float* in, int ldi, int nrows, c
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const float* wrow = W + (size_t)o * K;
-    for (int k = 0; k < K; k += 4) {
+    // eight weight loads in flight per thread (K % 32 == 0 in every use; the tail loop covers the rest): with one load per trip
+    // the loop was a chain of L2 round trips, ~100 us per workgroup
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        float4 w4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w4[u] = ldg4(wrow + k + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int w = g + i * G;
+                if (w < nrows) {
+                    const float4 x = ldg4(in + w * ldi + k + 4 * u);
+                    acc[i] = fmaf(x.x, w4[u].x, fmaf(x.y, w4[u].y, fmaf(x.z, w4[u].z, fmaf(x.w, w4[u].w, acc[i]))));
+                }
+            }
+    }
+    for (; k < K; k += 4) {
         const float4 w4 = ldg4(wrow + k);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -58,7 +76,17 @@ __device__ __forceinline__ void rows_mat(const float* in, int ldi, int nrows, co
             float acc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            for (int k = 0; k < K; ++k) {
+            int k = 0;
+            for (; k + 16 <= K; k += 16) {                        // sixteen weight loads in flight per thread
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = W[(size_t)(k + u) * O + o];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (w0 + i < nrows) acc[i] = fmaf(in[(w0 + i) * ldi + k + u], wv[u], acc[i]);
+            }
+            for (; k < K; ++k) {
                 const float wv = W[(size_t)k * O + o];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) if (w0 + i < nrows) acc[i] = fmaf(in[(w0 + i) * ldi + k], wv, acc[i]);
@@ -194,9 +222,18 @@ void word_prep_reduce_kernel(const float* __restrict__ slab, const float* __rest
     float* dWH = Q.p[8 * k]; float* dbWH = Q.p[8 * k + 1]; float* dSH = Q.p[8 * k + 2]; float* dbSH = Q.p[8 * k + 3]; float* dAK = Q.p[8 * k + 4];
     float* dbAK = Q.p[8 * k + 5]; float* dAQ = Q.p[8 * k + 6]; float* dbAQ = Q.p[8 * k + 7];
     if (x < ss) {
+        // eight partial sums keep eight loads in flight (a single running sum is one HBM round trip per slab: with ~128 slabs per
+        // layer that chain alone was ~350 us); the association is fixed, so the result is still bitwise reproducible
         const float* p = slab + (size_t)k * B * parts * ss + x;
-        float s = 0.f;
-        for (int b = 0; b < B * parts; ++b) s += p[(size_t)b * ss];
+        const int P = B * parts;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 8 <= P; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += p[(size_t)(b + u) * ss];
+        }
+        for (; b < P; ++b) a[0] += p[(size_t)b * ss];
+        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         const size_t o1 = (size_t)dl * dl, o2 = o1 + dl, o3 = o2 + o1, o4 = o3 + dl, o5 = o4 + (size_t)dl * D;
         if (x < o1) dAQ[x] = s; else if (x < o2) dbAQ[x - o1] = s; else if (x < o3) dAK[x - o2] = s; else if (x < o4) dbAK[x - o3] = s;
         else if (x < o5) dWH[x - o4] = s; else dbWH[x - o5] = s;
