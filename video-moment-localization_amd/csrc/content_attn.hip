@@ -290,7 +290,9 @@ __device__ __forceinline__ void stage_vectors(float* sS, float* sU, float* sQ, c
 template <int DL>
 static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + DL * LDW + DL + 64); }
 
-template <int DL, int WS>
+// ROWS / MEAN: which outputs exist.  Compile-time: a runtime `if (pointer)` inside the unrolled output loop costs a branch
+// per 16-feature block and stops hipcc from scheduling across the blocks.
+template <int DL, int WS, bool ROWS, bool MEAN>
 __global__ __launch_bounds__(256, 2)
 void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
@@ -342,10 +344,10 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
                     fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
                 }
                 const int d = 16 * j + 4 * kg;
-                if (cchat) {
+                if (ROWS) {
                     if (gc.ok && d < dl) stg4(cchat + (size_t)gc.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
                 }
-                if (ccmean) {                                       // mean over the clips of the quad (padding lanes hold 0)
+                if (MEAN) {                                         // mean over the clips of the quad (padding lanes hold 0)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                 // quad total in two DPP steps
                         const float t1 = o4[q] + nb<1>(o4[q]);
@@ -373,7 +375,7 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
 template <int DL>
 static size_t bwd_lds_bytes() { return sizeof(float) * (size_t)(64 * (DL + 4) + DL + 64 + 128 * (DL + 4) + 256 * LDP); }
 
-template <int DL, int WS>
+template <int DL, int WS, bool MEAN2, bool PERCELL>
 __global__ __launch_bounds__(512, 2)
 void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
                              const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
@@ -413,8 +415,8 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
         float4 raw[KJ], gq[KJ], gm[KJ];
         RowGeom g = row_geom16(cells, n + 4 * wave, seg_end, C, lane);
         fetch_rows16<DL>(raw, chat, g.row, dl, kg);
-        fetch_rows16<DL>(gq, dcchat, g_per_cell ? g.row / C : g.row, dl, kg);
-        if (dmean2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+        fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
+        if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
 
         for (int c0 = n; c0 < seg_end; c0 += 32) {                // rounds
             {
@@ -425,7 +427,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     const bool dok = g.ok && 16 * j + 4 * kg < dl;
                     const float gs = dok ? gscale : 0.f, ms = dok ? mscale : 0.f;
                     gv[j][0] = gq[j].x * gs; gv[j][1] = gq[j].y * gs; gv[j][2] = gq[j].z * gs; gv[j][3] = gq[j].w * gs;
-                    if (dmean2) {
+                    if (MEAN2) {
                         gv[j][0] = fmaf(gm[j].x, ms, gv[j][0]); gv[j][1] = fmaf(gm[j].y, ms, gv[j][1]);
                         gv[j][2] = fmaf(gm[j].z, ms, gv[j][2]); gv[j][3] = fmaf(gm[j].w, ms, gv[j][3]);
                     }
@@ -531,8 +533,8 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
             // next round's rows (past the segment: clamped to its last row, never used)
             g = row_geom16(cells, c0 + 32 + 4 * wave, seg_end, C, lane);
             fetch_rows16<DL>(raw, chat, g.row, dl, kg);
-            fetch_rows16<DL>(gq, dcchat, g_per_cell ? g.row / C : g.row, dl, kg);
-            if (dmean2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+            fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
+            if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
             __syncthreads();                                        // the round's da / dS / P rows are in LDS
             if (fq < DT) {
                 const int feat = 32 * fq + l31;
@@ -635,8 +637,18 @@ static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int*
 {
     (void)B;
     const int cpr = range_cells(N, 2 * attn_num_cus(), 16);      // two 256-thread workgroups per CU (203 registers)
-    hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS>), dim3(cdiv(N, cpr)), dim3(256), fwd_lds_bytes<DL>(), st, chat, cells, row_ptr, L, C,
-                       Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl));
+    const dim3 grid(cdiv(N, cpr));
+    const size_t lds = fwd_lds_bytes<DL>();
+    const float scale = 1.0f / sqrtf((float)dl);
+    if (cc_rows && cc_mean)
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, true, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+                           cc_rows, cc_mean, dl, Nq, N, cpr, scale);
+    else if (cc_rows)
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, true, false>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+                           cc_rows, cc_mean, dl, Nq, N, cpr, scale);
+    else
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, false, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+                           cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
@@ -670,8 +682,8 @@ size_t content_attn_bwd_ws_floats(int N, int B, int dl)
     return ((size_t)cdiv(N > 0 ? N : 1, cpr) + B + 1) * ((size_t)64 * dl + dl + 32) + 64;
 }
 
-template <int DL, int WS>
-static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
+template <int DL, int WS, bool MEAN2, bool PERCELL>
+static int bwd_v(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
                  const float* dmean2, float mscale)
@@ -679,18 +691,31 @@ static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const i
     const int cpr = content_attn_bwd_range_cells(N);
     static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bwd_lds_bytes<DL>());
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS>), dim3(cdiv(N, cpr)), dim3(512), bwd_lds_bytes<DL>(), st, chat, dcchat, cells, row_ptr, L, C,
+    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), dim3(cdiv(N, cpr)), dim3(512), bwd_lds_bytes<DL>(), st, chat, dcchat, cells, row_ptr, L, C,
                        Mq, uq, what, shat, qmask, dchat, ws, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
     SMIN_LAUNCH_CHECK();
     const int slab_sz = 64 * dl + dl + 32;
     hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, ws, row_ptr, L, dl, Nq, cpr, dMq, dwhat, dshat, duq);
     SMIN_LAUNCH_CHECK();
     return 0;
+}
+
+template <int DL, int WS>
+static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
+                 const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                 float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
+                 const float* dmean2, float mscale)
+{
+    if (dmean2)
+        return bwd_v<DL, WS, true, false>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, dmean2, mscale);
+    if (g_per_cell)
+        return bwd_v<DL, WS, false, true>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 1, gscale, nullptr, mscale);
+    return bwd_v<DL, WS, false, false>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, nullptr, mscale);
 }
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
