@@ -169,6 +169,8 @@ def main():
         model.overlap_boundary = False
     if os.environ.get("SMIN_NO_PREP_OVERLAP"):
         model.overlap_prep = False
+    if os.environ.get("SMIN_NODE_GRAPH"):                    # A/B switch: one autograd node per module instead of the fused core
+        model.fused_core = False
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
     net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)

@@ -299,6 +299,14 @@ int smin_build_cells(void* stream, const uint8_t* mask, int B, int L, int all_ce
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);
 
+/* ---- host helpers of the fused step: many small tensors in one launch.  src/dst/rows/cols/srcs are HOST arrays.
+ *   smin_transpose_batch: dst[m] [cols][rows] = src[m]^T for n <= SMIN_BATCH_MAX row-major matrices src[m] [rows][cols]
+ *     (the W^T operands of the input-gradient contractions; the reference transposes inside autograd, models.py every nn.Linear);
+ *   smin_sum_lists: out[i] = sum_k srcs[k][i] in list order (gradients of f_s / f_w, which every layer consumes). */
+#define SMIN_BATCH_MAX 32
+int smin_transpose_batch(void* stream, const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols, int n);
+int smin_sum_lists(void* stream, const float* const* srcs, int n, size_t numel, float* out);
+
 /* ---- stand-alone fp32 MFMA GEMM  C[M][N] = A[M][K] * B[N][K]^T  (used by tests and bench.py's
  * roofline probe; same engine as every contraction above). */
 int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K);

@@ -52,5 +52,5 @@ def test_rccl_world1_two_stream_step_under_ddp():
     assert r["backend"] == "nccl" and r["world"] == 1
     assert r["native_so"]
     assert r["flags_after"][0] is True, "the boundary unit must stay on the second stream under RCCL"
-    assert r["overrides"] == {"overlap_prep": False}
+    assert r["overrides"] == {}, "the one-node step keeps both overlaps under RCCL"
     assert r["worst_rel"] <= 1e-6, (r["worst_name"], r["worst_rel"])

@@ -7,6 +7,9 @@
 
 namespace smin {
 
+// HAS_*: which addends exist -- template parameters, not runtime pointer tests: a per-element "load or zero" select on a runtime
+// condition makes hipcc branch around every load of the unrolled chunk (and wait for each), cdna_hip_programming.md 5, item 4(c)
+template <bool HAS_BIAS, bool HAS_ROWS, bool HAS_CELLS>
 struct EpLinearRows {
     const float* bias; const float* add_rows; const float* add_cells; int C; float* out;
     struct Add { float4 r, c; };
@@ -14,13 +17,15 @@ struct EpLinearRows {
         chunk_rows_f4_pre<Add>(Ws, row0, col0, ncols, M, N, lane,
             [&](int row, int col) {
                 Add a;
-                a.r = add_rows ? ldg4(add_rows + (size_t)row * N + col) : f4zero();
-                a.c = add_cells ? ldg4(add_cells + (size_t)(row / C) * N + col) : f4zero();
+                a.r = HAS_ROWS ? ldg4(add_rows + (size_t)row * N + col) : f4zero();
+                a.c = HAS_CELLS ? ldg4(add_cells + (size_t)(row / C) * N + col) : f4zero();
                 return a;
             },
             [&](int row, int col, float4 v, const Add& a) {
-                if (bias) v = f4add(v, ldg4(bias + col));
-                stg4(out + (size_t)row * N + col, f4add(f4add(v, a.r), a.c));
+                if (HAS_BIAS) v = f4add(v, ldg4(bias + col));
+                if (HAS_ROWS) v = f4add(v, a.r);
+                if (HAS_CELLS) v = f4add(v, a.c);
+                stg4(out + (size_t)row * N + col, v);
             });
     }
 };
@@ -72,9 +77,20 @@ extern "C" int smin_linear_rows_fwd(void* stream, const float* const* xs, int ns
 {
     SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1 && nseg >= 1 && nseg <= 4);
     if (R == 0) return 0;
-    const EpLinearRows ep{bias, add_rows, add_cells, C, y};
-    if (nseg == 1) return launch_gemm_nt((hipStream_t)stream, PlainMat{xs[0], K}, PlainMat{W, K}, ep, R, O, K);
-    return launch_gemm_nt((hipStream_t)stream, cat_of(xs, nseg, K), PlainMat{W, nseg * K}, ep, R, O, nseg * K);
+    hipStream_t st = (hipStream_t)stream;
+    auto run = [&](auto ep) {
+        if (nseg == 1) return launch_gemm_nt(st, PlainMat{xs[0], K}, PlainMat{W, K}, ep, R, O, K);
+        return launch_gemm_nt(st, cat_of(xs, nseg, K), PlainMat{W, nseg * K}, ep, R, O, nseg * K);
+    };
+    // the combinations the hosts use: plain, bias, bias + rows + cells, rows only, bias + rows
+    if (!add_rows && !add_cells) return bias ? run(EpLinearRows<true, false, false>{bias, add_rows, add_cells, C, y})
+                                             : run(EpLinearRows<false, false, false>{bias, add_rows, add_cells, C, y});
+    if (add_rows && add_cells) return bias ? run(EpLinearRows<true, true, true>{bias, add_rows, add_cells, C, y})
+                                           : run(EpLinearRows<false, true, true>{bias, add_rows, add_cells, C, y});
+    if (add_rows) return bias ? run(EpLinearRows<true, true, false>{bias, add_rows, add_cells, C, y})
+                              : run(EpLinearRows<false, true, false>{bias, add_rows, add_cells, C, y});
+    return bias ? run(EpLinearRows<true, false, true>{bias, add_rows, add_cells, C, y})
+                : run(EpLinearRows<false, false, true>{bias, add_rows, add_cells, C, y});
 }
 
 extern "C" size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot)

@@ -130,6 +130,12 @@ std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, 
 
 Tensor undef() { return Tensor(); }
 
+// parameter order (modules.py: SMIN._native_params): video encoder 3, LSTM 16, 20 per SMI layer, localization 8
+enum { P_VE_W = 0, P_VE_B, P_PE, P_LSTM = 3, P_LAYER0 = 19 };
+enum { L_CH_W = 0, L_CH_B, L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_C_W, L_C_B, L_AQ_W, L_AQ_B, L_AK_W, L_AK_B, L_BQ_W, L_BQ_B, L_BK_W, L_BK_B, L_FB_W, L_FB_B, L_FC_W,
+       L_FC_B, L_COUNT };
+
+
 // ---------------------------------------------------------------- autograd nodes (one per reference module body)
 
 // f = ((x W^T + b + pe[t]) * vmask) * f_s   -- VideoEncoder.forward + Backbone's Hadamard product (models.py:25-36, 81-83)
@@ -585,12 +591,542 @@ struct LossNode : torch::autograd::Function<LossNode> {
     }
 };
 
-// ---------------------------------------------------------------- the model
 
-// parameter order (modules.py: SMIN._native_params): video encoder 3, LSTM 16, 20 per SMI layer, localization 8
-enum { P_VE_W = 0, P_VE_B, P_PE, P_LSTM = 3, P_LAYER0 = 19 };
-enum { L_CH_W = 0, L_CH_B, L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_C_W, L_C_B, L_AQ_W, L_AQ_B, L_AK_W, L_AK_B, L_BQ_W, L_BQ_B, L_BK_W, L_BK_B, L_FB_W, L_FB_B, L_FC_W,
-       L_FC_B, L_COUNT };
+// ---------------------------------------------------------------- the fused core
+// ProposalGeneration + every SMI layer + Localization (models.py:101-126, 306-344) as ONE autograd node: forward and backward
+// are straight-line sequences of the C entry points with hand-placed stream forks.  What the node-per-module graph above pays
+// and this does not: ~60 engine node visits, the engine's out-of-place sums for every tensor with several consumers
+// (f_s, f_w, the boundary features, the parameters shared between layers -- ~45 tiny launches per step), a transposed copy per
+// weight per backward call (one batched launch here) and the autograd bookkeeping of the parameter products.
+struct LayerState {
+    Tensor fm, hbar, fb, bu, Qb, Kb, P, baq, bqv, A, Hs, chat, cc, ccmean, cum, x1, consts, Wcat;
+    std::vector<Tensor> Pcat;
+};
+struct LstmState { Tensor x, Hout, G, Cs, Wih, Whh; };
+struct CoreState {
+    Tensor vx, fv, vmaskf, len32, last, f, fw, fs, qmf, lmf, cells, row_ptr, cellmap, Wch_all, what, kb, Mq, uq, shat, pm, psea, fm_out, wb;
+    LstmState lstm[2];
+    std::vector<LayerState> layer;
+};
+template <class F>
+void visit_state(CoreState& s, F&& fn)
+{
+    for (Tensor* t : {&s.vx, &s.fv, &s.vmaskf, &s.len32, &s.last, &s.f, &s.fw, &s.fs, &s.qmf, &s.lmf, &s.cells, &s.row_ptr, &s.cellmap, &s.Wch_all, &s.what, &s.kb, &s.Mq,
+                      &s.uq, &s.shat, &s.pm, &s.psea, &s.fm_out, &s.wb})
+        fn(*t);
+    for (auto& l : s.lstm)
+        for (Tensor* t : {&l.x, &l.Hout, &l.G, &l.Cs, &l.Wih, &l.Whh}) fn(*t);
+    for (auto& l : s.layer) {
+        for (Tensor* t : {&l.fm, &l.hbar, &l.fb, &l.bu, &l.Qb, &l.Kb, &l.P, &l.baq, &l.bqv, &l.A, &l.Hs, &l.chat, &l.cc, &l.ccmean, &l.cum, &l.x1, &l.consts, &l.Wcat})
+            fn(*t);
+        for (auto& p : l.Pcat) fn(p);
+    }
+}
+void size_state(CoreState& s, int64_t nl)
+{
+    s.layer.resize(nl);
+    for (int64_t k = 0; k < nl; ++k) s.layer[k].Pcat.resize((k + 3) / 4);
+}
+
+// W^T of every listed matrix, one launch per 32 matrices
+std::vector<Tensor> transpose_all(const std::vector<Tensor>& ws)
+{
+    std::vector<Tensor> out;
+    for (size_t lo = 0; lo < ws.size(); lo += SMIN_BATCH_MAX) {
+        const size_t n = std::min(ws.size() - lo, (size_t)SMIN_BATCH_MAX);
+        const float* src[SMIN_BATCH_MAX]; float* dst[SMIN_BATCH_MAX]; int32_t rows[SMIN_BATCH_MAX], cols[SMIN_BATCH_MAX];
+        for (size_t m = 0; m < n; ++m) {
+            const Tensor& w = ws[lo + m];
+            TORCH_CHECK(w.dim() == 2 && w.is_contiguous(), "transpose_all: contiguous matrices only");
+            out.push_back(at::empty({w.size(1), w.size(0)}, w.options()));
+            src[m] = fp(w); dst[m] = fpm(out.back()); rows[m] = i32(w.size(0)); cols[m] = i32(w.size(1));
+        }
+        SMIN_CK(smin_transpose_batch(cur(), src, dst, rows, cols, i32(n)));
+    }
+    return out;
+}
+Tensor sum_list(const std::vector<Tensor>& ts)
+{
+    TORCH_CHECK(!ts.empty() && ts.size() <= SMIN_BATCH_MAX, "sum_list: 1..", SMIN_BATCH_MAX, " tensors");
+    if (ts.size() == 1) return ts[0];
+    const float* p[SMIN_BATCH_MAX];
+    for (size_t k = 0; k < ts.size(); ++k) { TORCH_CHECK(ts[k].is_contiguous() && ts[k].numel() == ts[0].numel(), "sum_list: shapes differ"); p[k] = fp(ts[k]); }
+    Tensor out = at::empty_like(ts[0]);
+    SMIN_CK(smin_sum_lists(cur(), p, i32(ts.size()), (size_t)ts[0].numel(), fpm(out)));
+    return out;
+}
+
+struct SminCore : torch::autograd::Function<SminCore> {
+    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2 };
+    enum { N_FIXED = 13 };          // forward arguments ahead of the parameter list (tensors and scalars alike take one gradient slot)
+
+    static variable_list forward(AutogradContext* ctx, Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask,
+                                 Tensor moment_mask, int64_t T, int64_t L, int64_t C, int64_t nl, int64_t maxq, int64_t H, int64_t flags, at::TensorList prm_in)
+    {
+        std::vector<Tensor> all;
+        for (const Tensor& p : prm_in) all.push_back(cont(p));
+        std::vector<Tensor> prm(all.begin() + P_LAYER0, all.end());                // the SMI layers' and the localization head's parameters
+        const at::Device dev = video_features.device();
+        const auto opt = video_features.options();
+        const int64_t Bq = video_features.size(0), Tn = video_features.size(1), Nq_in = query_features.size(1);
+        TORCH_CHECK(Tn == T, "ProposalGeneration was built for T=", T, " but got ", Tn, " frames");
+        const int B = i32(Bq), D = i32(all[P_VE_W].size(0)), Nq = i32(maxq), dl = i32(prm[L_CH_W].size(0)), Li = i32(L), Ci = i32(C), Ti = i32(T);
+        auto lp = [&](int64_t k, int which) -> const Tensor& { return prm[k * L_COUNT + which]; };
+        const Tensor* loc = &prm[nl * L_COUNT];
+        HStream curs = c10::hip::getCurrentHIPStream(dev.index());
+        HStream side = (flags & F_OVERLAP_BOUNDARY) ? side_stream(dev.index()) : curs;
+        HStream prep = (flags & F_OVERLAP_PREP) ? side : curs;
+        CoreState st;
+        size_state(st, nl);
+
+        // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
+        Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
+        Tensor host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+        host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+        hipEvent_t count_ready = next_event();
+        TORCH_CHECK(hipEventRecord(count_ready, curs.stream()) == hipSuccess, "hipEventRecord failed");
+
+        // ---- backbone (models.py:38-83): BiLSTM x 2, sentence feature, fused video encoder
+        Tensor qm = query_mask.reshape({Bq, -1});
+        Tensor length = qm.sum(1);
+        st.len32 = length.to(at::kInt);
+        Tensor x = cont(query_features);
+        for (int layer = 0; layer < 2; ++layer) {
+            const Tensor* w = &all[P_LSTM + 8 * layer];
+            LstmState& ls = st.lstm[layer];
+            const int In = i32(x.size(2)), Hh = i32(H);
+            ls.x = x;
+            ls.Wih = at::cat({w[0], w[4]});                                        // [8H, In]
+            Tensor bias = at::cat({w[2] + w[3], w[6] + w[7]});                     // [8H]
+            ls.Whh = at::stack({w[1], w[5]});                                      // [2, 4H, H]
+            Tensor W4 = ls.Whh.view({2, 4, H, H}).permute({0, 3, 2, 1}).contiguous();   // [2, k, u, gate]
+            ls.G = at::empty({Bq, Nq_in, 2, 4 * H}, opt); ls.Hout = at::empty({Bq, Nq_in, 2 * H}, opt); ls.Cs = at::empty({Bq, Nq_in, 2, H}, opt);
+            SMIN_CK(smin_bilstm_layer_fwd(cur(), fp(x), fp(ls.Wih), fp(bias), fp(W4), ip(st.len32), B, i32(Nq_in), In, Hh, fpm(ls.G), fpm(ls.Hout), fpm(ls.Cs)));
+            x = ls.Hout;
+        }
+        Tensor fw = x;
+        if (Nq_in < maxq) fw = at::constant_pad_nd(fw, {0, 0, 0, maxq - Nq_in}, 0);
+        fw = fw.contiguous();
+        st.last = (length.to(at::kLong) - 1).clamp_min(0).view({Bq, 1, 1}).expand({Bq, 1, H}).contiguous();
+        Tensor fs = at::cat({fw.slice(2, 0, H).gather(1, st.last).view({Bq, H}), fw.select(1, 0).slice(1, H)}, 1);
+        st.vx = cont(video_features); st.vmaskf = cont(fl(video_mask.reshape({Bq * Tn})));
+        st.fv = at::empty({Bq, T, (int64_t)D}, opt);
+        Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
+        SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), fp(fs), B, Ti, i32(st.vx.size(2)), D, fpm(st.fv), fpm(f)));
+
+        // ---- layout, part 2
+        TORCH_CHECK(hipEventSynchronize(count_ready) == hipSuccess, "hipEventSynchronize failed");
+        const int64_t N = host_n.const_data_ptr<int64_t>()[0];
+        const int n = i32(N);
+        Tensor cells, row_ptr, cellmap;
+        {
+            auto io = at::TensorOptions().dtype(at::kInt).device(dev);
+            Tensor mask8 = mm.contiguous().view(at::kByte);
+            cells = at::empty({N, 4}, io); row_ptr = at::empty({Bq * L + 1}, io); cellmap = at::empty({Bq, L, L}, io);
+            SMIN_CK(smin_build_cells(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), B, Li, 0, cells.data_ptr<int32_t>(), row_ptr.data_ptr<int32_t>(),
+                                     cellmap.data_ptr<int32_t>()));
+        }
+        Tensor qmf = cont(fl(qm)), lmf = cont(fl(length_mask));
+        st.f = f; st.fw = fw; st.fs = fs; st.qmf = qmf; st.lmf = lmf; st.cells = cells; st.row_ptr = row_ptr; st.cellmap = cellmap;
+
+        // ---- parameter-only and word-side work on the second stream
+        std::vector<Tensor> bcat(nl);
+        wait_stream(prep, curs);
+        {
+            StreamScope sc(prep);
+            Tensor bsum;
+            std::vector<Tensor> wch;
+            for (int64_t k = 0; k < nl; ++k) {
+                LayerState& ls = st.layer[k];
+                ls.consts = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
+                bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
+                wch.push_back(lp(k, L_CH_W));
+                for (int64_t lo = 0; lo < k; lo += 4) {
+                    std::vector<Tensor> parts;
+                    for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
+                    ls.Pcat[lo / 4] = parts.size() == 1 ? parts[0] : at::cat(parts, 1);
+                }
+                ls.Wcat = at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1);
+                bcat[k] = lp(k, L_FB_B) + lp(k, L_FC_B);
+            }
+            st.Wch_all = nl == 1 ? wch[0] : at::cat(wch);
+            st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
+            std::vector<const float*> pp;
+            for (int64_t k = 0; k < nl; ++k)
+                for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) pp.push_back(fp(lp(k, which)));
+            st.what = at::empty({nl, B, Nq, dl}, opt); st.kb = at::empty({nl, B, Nq, dl}, opt); st.Mq = at::empty({nl, B, Nq, dl}, opt);
+            st.shat = at::empty({nl, B, dl}, opt); st.uq = at::empty({nl, B, Nq}, opt);
+            SMIN_CK(smin_word_prep_fwd(cur(), fp(fw), fp(fs), fp(qmf), pp.data(), i32(nl), B, Nq, D, dl, fpm(st.what), fpm(st.shat), fpm(st.kb), fpm(st.Mq), fpm(st.uq)));
+        }
+        Tensor bb = at::cat({loc[3], loc[5], loc[7]});
+        wait_stream(curs, prep);
+        if (prep != curs) {
+            for (const Tensor* t : {&st.Wch_all, &st.wb, &st.what, &st.kb, &st.Mq, &st.uq, &st.shat}) record_stream(*t, curs);
+            for (int64_t k = 0; k < nl; ++k) {
+                record_stream(st.layer[k].consts, curs); record_stream(st.layer[k].Wcat, curs); record_stream(bcat[k], curs);
+                for (auto& p : st.layer[k].Pcat) record_stream(p, curs);
+            }
+            for (const Tensor* t : {&fw, &fs, &qmf}) record_stream(*t, prep);
+        }
+        if (side != curs)
+            for (const Tensor* t : {&fw, &fs, &qmf, &lmf, &cells, &row_ptr, &cellmap}) record_stream(*t, side);
+
+        // ---- proposal map (f_m, f_b) and every layer's clip-window term of chat
+        Tensor fm = at::empty({N, D}, opt), fb = at::empty({B, L, D}, opt);
+        {
+            auto ws = scratch((size_t)8 * B * (T + 1) * std::max<int64_t>(D, nl * dl), dev);
+            SMIN_CK(smin_proposal_map_fwd(cur(), fp(f), ip(cells), n, B, Ti, Li, Ci, D, nullptr, fpm(fm), fpm(fb), ws.p, ws.n));
+        }
+        Tensor pgs = at::empty({nl, N * C, dl}, opt);
+        {
+            Tensor g_all = at::empty({(int64_t)B * T, nl * dl}, opt);
+            const float* xs[1] = {fp(f)};
+            SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(st.Wch_all), nullptr, nullptr, nullptr, 1, i32(B * T), i32(nl * dl), D, fpm(g_all)));
+            auto ws = scratch((size_t)8 * B * (T + 1) * std::max<int64_t>(D, nl * dl), dev);
+            SMIN_CK(smin_clip_window_means_fwd(cur(), fp(g_all), fp(st.layer[0].consts), dl, ip(cells), n, B, Ti, Li, Ci, dl, i32(nl), fpm(pgs), ws.p, ws.n));
+        }
+
+        Tensor cumean = fm, Hs;                                                    // mean_c f_c of the proposal map is f_m
+        for (int64_t k = 0; k < nl; ++k) {
+            LayerState& ls = st.layer[k];
+            const bool lastl = k == nl - 1;
+            ls.fm = fm; ls.fb = fb;
+            ls.hbar = at::empty_like(fm);
+            SMIN_CK(smin_gate_fwd(cur(), fp(fm), fp(fs), ip(cells), n, D, fpm(ls.hbar)));
+            // boundary unit on the second stream beside the content stream; joins before the moment unit
+            wait_stream(side, curs);
+            {
+                StreamScope sc(side);
+                ls.bu = at::empty_like(fb); ls.Qb = at::empty_like(fb); ls.baq = at::empty_like(fb); ls.bqv = at::empty_like(fb); ls.Kb = at::empty_like(fw);
+                ls.P = at::empty({B, L, Nq}, opt); ls.A = at::empty({B, L, L}, opt);
+                SMIN_CK(smin_boundary_unit_fwd(cur(), fp(fb), fp(fw), fp(fs), fp(ls.hbar), ip(cells), ip(row_ptr), n, B, Li, Nq, D, fp(lp(k, L_BQ_W)), fp(lp(k, L_BQ_B)),
+                                               fp(lp(k, L_BK_W)), fp(lp(k, L_BK_B)), fp(qmf), fp(lmf), fpm(ls.bu), fpm(ls.Qb), fpm(ls.Kb), fpm(ls.P), fpm(ls.baq),
+                                               fpm(ls.bqv), fpm(ls.A)));
+            }
+            if (side != curs) { record_stream(fb, side); record_stream(ls.hbar, side); }
+            // chat_k = clip-window term + [cc_0 | ..] Pcat^T + const_k + (Hs Wch^T per cell)
+            Tensor chat = pgs[k];
+            ls.Hs = Hs;
+            for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
+                Tensor hp;
+                if (lo == 0) {
+                    hp = at::empty({N, dl}, opt);
+                    const float* xs[1] = {fp(Hs)};
+                    SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_CH_W)), nullptr, nullptr, nullptr, 1, n, dl, D, fpm(hp)));
+                }
+                const int nseg = i32(std::min<int64_t>(4, k - lo));
+                const float* xs[4];
+                for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
+                Tensor y = at::empty({N * C, dl}, opt);
+                SMIN_CK(smin_linear_rows_fwd(cur(), xs, nseg, fp(ls.Pcat[part]), lo == 0 ? fp(ls.consts) : nullptr, fp(chat), fp(hp), Ci, i32(N * C), dl, dl, fpm(y)));
+                chat = y;
+            }
+            ls.chat = chat;
+            ls.cc = at::empty({lastl ? 0 : N * C, dl}, opt); ls.ccmean = at::empty({N, dl}, opt);
+            SMIN_CK(smin_content_attn_fwd(cur(), fp(chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]), fp(st.shat[k]), fp(qmf),
+                                          lastl ? nullptr : fpm(ls.cc), fpm(ls.ccmean)));
+            ls.cum = at::empty({N, D}, opt);
+            {
+                const float* xs[1] = {fp(ls.ccmean)};
+                SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_C_W)), fp(lp(k, L_C_B)), fp(cumean), fp(ls.hbar), 1, n, D, dl, fpm(ls.cum)));
+            }
+            if (!lastl) Hs = Hs.defined() ? Hs + ls.hbar : ls.hbar;
+            wait_stream(curs, side);
+            if (side != curs) for (const Tensor* t : {&ls.bu, &ls.Qb, &ls.Kb, &ls.P, &ls.baq, &ls.bqv, &ls.A}) record_stream(*t, curs);
+            ls.x1 = at::empty_like(fm);                                            // f_b[i] * f_b[j], kept for the weight gradient
+            Tensor mu = at::empty_like(fm);
+            SMIN_CK(smin_pair_product(cur(), fp(ls.bu), ip(cells), n, Li, D, fpm(ls.x1)));
+            SMIN_CK(smin_moment_unit_fwd(cur(), fp(ls.cum), fp(fm), fp(ls.bu), ip(cells), n, B, Li, D, fp(ls.Wcat), fp(bcat[k]), fpm(mu), fp(ls.x1)));
+            fm = mu; cumean = ls.cum; fb = ls.bu;
+        }
+        // Localization (models.py:335-344)
+        Tensor pm = at::empty({B, L, L}, opt), psea = at::empty({3, B, L}, opt);
+        SMIN_CK(smin_score_map_fwd(cur(), fp(fm), fp(fb), ip(cells), n, B, Li, D, fp(loc[0]), fp(loc[1]), fp(st.wb), fp(bb), fp(lmf), fpm(pm), fpm(psea)));
+        st.pm = pm; st.psea = psea; st.fm_out = fm;
+
+        variable_list flat;
+        visit_state(st, [&](Tensor& t) { flat.push_back(t); });
+        for (auto& p : all) flat.push_back(p);
+        ctx->save_for_backward(flat);
+        ctx->saved_data["d"] = std::vector<int64_t>{N, T, L, C, nl, flags, H, Nq_in};
+        return {pm, psea};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g)
+    {
+        auto d = ctx->saved_data["d"].toIntVector();
+        const int64_t N = d[0], T = d[1], L = d[2], C = d[3], nl = d[4], flags = d[5], H = d[6], Nq_in = d[7];
+        auto sv = ctx->get_saved_variables();
+        CoreState st;
+        size_state(st, nl);
+        size_t cursor = 0;
+        visit_state(st, [&](Tensor& t) { t = sv[cursor++]; });
+        std::vector<Tensor> all(sv.begin() + cursor, sv.end());
+        std::vector<Tensor> prm(all.begin() + P_LAYER0, all.end());
+        auto lp = [&](int64_t k, int which) -> const Tensor& { return prm[k * L_COUNT + which]; };
+        const Tensor* loc = &prm[nl * L_COUNT];
+        const Tensor &f = st.f, &fw = st.fw, &fs = st.fs, &qmf = st.qmf, &lmf = st.lmf, &cells = st.cells, &row_ptr = st.row_ptr, &cellmap = st.cellmap;
+        const at::Device dev = f.device();
+        const auto opt = f.options();
+        const int B = i32(f.size(0)), D = i32(f.size(2)), Nq = i32(fw.size(1)), dl = i32(prm[L_CH_W].size(0)), n = i32(N), Li = i32(L), Ci = i32(C), Ti = i32(T);
+        HStream curs = c10::hip::getCurrentHIPStream(dev.index());
+        HStream side = (flags & F_OVERLAP_BOUNDARY) ? side_stream(dev.index()) : curs;
+        std::vector<Tensor> dprm(prm.size());
+        auto dlp = [&](int64_t k, int which) -> Tensor& { return dprm[k * L_COUNT + which]; };
+        auto acc = [](Tensor& into, const Tensor& t) { if (into.defined()) into.add_(t); else into = t; };
+
+        // ---- W^T of every contraction weight, one launch
+        enum { TR_CH = 0, TR_C, TR_CAT, TR_BQ, TR_BK, TR_PER_LAYER };
+        std::vector<Tensor> tr_in;
+        for (int64_t k = 0; k < nl; ++k) {
+            tr_in.push_back(lp(k, L_CH_W)); tr_in.push_back(lp(k, L_C_W)); tr_in.push_back(st.layer[k].Wcat); tr_in.push_back(lp(k, L_BQ_W)); tr_in.push_back(lp(k, L_BK_W));
+        }
+        const size_t tr_pcat0 = tr_in.size();
+        for (int64_t k = 0; k < nl; ++k) for (auto& p : st.layer[k].Pcat) tr_in.push_back(p);
+        tr_in.push_back(st.Wch_all);
+        tr_in.push_back(st.lstm[0].Wih); tr_in.push_back(st.lstm[1].Wih);
+        std::vector<Tensor> tr = transpose_all(tr_in);
+        auto trk = [&](int64_t k, int which) -> const Tensor& { return tr[k * TR_PER_LAYER + which]; };
+        std::vector<std::vector<Tensor>> PcatT(nl);
+        { size_t i = tr_pcat0; for (int64_t k = 0; k < nl; ++k) for (size_t p = 0; p < st.layer[k].Pcat.size(); ++p) PcatT[k].push_back(tr[i++]); }
+        const Tensor &Wch_allT = tr[tr.size() - 3], *WihT = &tr[tr.size() - 2];
+        if (side != curs) for (int64_t k = 0; k < nl; ++k) { record_stream(trk(k, TR_BQ), side); record_stream(trk(k, TR_BK), side); }
+
+        // ---- Localization
+        const Tensor& bu_last = st.layer[nl - 1].bu;
+        Tensor dpm = g[0].defined() ? cont(g[0]) : at::zeros_like(st.pm), dpsea = g[1].defined() ? cont(g[1]) : at::zeros_like(st.psea);
+        Tensor dfm = at::empty({N, D}, opt), dfb_next = at::empty({B, L, D}, opt);
+        {
+            Tensor dwm = at::empty({D}, opt), dbm = at::empty({1}, opt), dwb = at::empty({3, D}, opt), dbb = at::empty({3}, opt);
+            auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
+            SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), fp(dpsea), fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb), fp(lmf),
+                                       fpm(dfm), fpm(dfb_next), fpm(dwm), fpm(dbm), fpm(dwb), fpm(dbb), ws.p, ws.n));
+            Tensor* dloc = &dprm[nl * L_COUNT];
+            dloc[0] = dwm.view_as(loc[0]); dloc[1] = dbm.view_as(loc[1]);
+            for (int h = 0; h < 3; ++h) { dloc[2 + 2 * h] = dwb[h].view_as(loc[2 + 2 * h]); dloc[3 + 2 * h] = dbb.slice(0, h, h + 1).view_as(loc[3 + 2 * h]); }
+        }
+
+        std::vector<Tensor> dcc(nl), dHs(nl), dchat(nl), dconsts(nl), dfs_parts, dfw_parts;
+        std::vector<std::vector<Tensor>> dPcat(nl);
+        Tensor dwhat = at::empty_like(st.what), dshat = at::empty_like(st.shat), dMq = at::empty_like(st.Mq), duq = at::empty_like(st.uq);
+        if (N == 0) { dwhat.zero_(); dshat.zero_(); dMq.zero_(); duq.zero_(); }
+        Tensor dcum_next;                                                          // gradient of cum_k from layer k+1's clip-mean chain
+        for (int64_t k = nl - 1; k >= 0; --k) {
+            LayerState& ls = st.layer[k];
+            // moment unit: dmu -> d cum (its chain gradient folded in), d bu, weight gradients; the residual gradient is dmu itself
+            Tensor dcum = at::empty({N, D}, opt), dfb_mu = at::empty({B, L, D}, opt), dWcat = at::empty_like(ls.Wcat), dbcat = at::empty({D}, opt);
+            {
+                auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
+                SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), fpm(dcum), fpm(dfb_mu),
+                                             fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, fp(dcum_next), fp(ls.x1)));
+            }
+            dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
+            dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
+            // boundary unit on the second stream
+            Tensor dfb_k, dhbar_b;
+            wait_stream(side, curs);
+            {
+                StreamScope sc(side);
+                const float* two[2] = {fp(dfb_next), fp(dfb_mu)};
+                Tensor dbu = at::empty({B, L, D}, opt);
+                SMIN_CK(smin_sum_lists(cur(), two, 2, (size_t)dbu.numel(), fpm(dbu)));
+                dfb_k = at::empty({B, L, D}, opt); dhbar_b = at::empty({N, D}, opt);
+                Tensor dfw = at::empty_like(fw), dfs = at::empty_like(fs);
+                Tensor dWq = at::empty({D, D}, opt), dbq = at::empty({D}, opt), dWk = at::empty({D, D}, opt), dbk = at::empty({D}, opt);
+                const size_t nbytes = 4 * ((size_t)2 * B * L * L + (size_t)3 * B * L * D + (size_t)B * L * Nq + (size_t)B * Nq * D + (size_t)2 * 64 * ((size_t)D * D + D)) + 4096;
+                auto ws = scratch(nbytes, dev);
+                SMIN_CK(smin_boundary_unit_bwd(cur(), fp(dbu), fp(ls.fb), fp(fw), fp(fs), fp(ls.hbar), ip(cells), ip(row_ptr), n, B, Li, Nq, D, fp(trk(k, TR_BQ)), fp(trk(k, TR_BK)),
+                                               fp(qmf), fp(lmf), fp(ls.Qb), fp(ls.Kb), fp(ls.P), fp(ls.baq), fp(ls.bqv), fp(ls.A), fpm(dfb_k), fpm(dfw), fpm(dfs), fpm(dhbar_b),
+                                               fpm(dWq), fpm(dbq), fpm(dWk), fpm(dbk), ws.p, ws.n));
+                dlp(k, L_BQ_W) = dWq; dlp(k, L_BQ_B) = dbq; dlp(k, L_BK_W) = dWk; dlp(k, L_BK_B) = dbk;
+                dfs_parts.push_back(dfs); dfw_parts.push_back(dfw);
+                if (side != curs) {
+                    record_stream(dfb_next, side); record_stream(dfb_mu, side);
+                    for (const Tensor* t : {&dfb_k, &dhbar_b, &dfw, &dfs, &dWq, &dbq, &dWk, &dbk}) record_stream(*t, curs);
+                }
+            }
+            // clip-mean update cum = ccmean Wc^T + b + cumean + hbar: d ccmean, weight gradients; d cumean = d hbar = dcum
+            Tensor dccmean = at::empty({N, dl}, opt);
+            {
+                Tensor dWc = at::empty_like(lp(k, L_C_W)), dbc = at::empty({D}, opt);
+                const float* xs[1] = {fp(ls.ccmean)}; float* dxs[1] = {fpm(dccmean)};
+                auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(n, D, dl), dev);
+                SMIN_CK(smin_linear_rows_bwd(cur(), fp(dcum), xs, 1, fp(trk(k, TR_C)), n, D, dl, dxs, fpm(dWc), fpm(dbc), ws.p, ws.n));
+                acc(dlp(k, L_C_W), dWc); acc(dlp(k, L_C_B), dbc);
+            }
+            // attention core
+            dchat[k] = at::empty({N * C, dl}, opt);
+            if (N > 0) {
+                auto ws = scratch(smin_content_attn_bwd_workspace_bytes(n, B, Ci, dl), dev);
+                SMIN_CK(smin_content_attn_bwd(cur(), fp(dcc[k]), fp(dccmean), fp(ls.chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]),
+                                              fp(st.shat[k]), fp(qmf), fpm(dchat[k]), fpm(dMq[k]), fpm(duq[k]), fpm(dwhat[k]), fpm(dshat[k]), ws.p, ws.n));
+            }
+            // chat_k's contraction over the earlier layers' attention outputs, and its per-cell gate term
+            for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
+                const int nseg = i32(std::min<int64_t>(4, k - lo));
+                const float* xs[4]; float* dxs[4];
+                std::vector<Tensor> dx(nseg);
+                for (int sgm = 0; sgm < nseg; ++sgm) { xs[sgm] = fp(st.layer[lo + sgm].cc); dx[sgm] = at::empty({N * C, dl}, opt); dxs[sgm] = fpm(dx[sgm]); }
+                Tensor dP = at::empty_like(ls.Pcat[part]);
+                if (lo == 0) dconsts[k] = at::empty({dl}, opt);
+                auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(i32(N * C), dl, nseg * dl), dev);
+                SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, fp(PcatT[k][part]), i32(N * C), dl, dl, dxs, fpm(dP), lo == 0 ? fpm(dconsts[k]) : nullptr, ws.p, ws.n));
+                dPcat[k].push_back(dP);
+                for (int sgm = 0; sgm < nseg; ++sgm) acc(dcc[lo + sgm], dx[sgm]);
+            }
+            if (k > 0) {
+                Tensor dhp = at::empty({N, dl}, opt);
+                SMIN_CK(smin_group_sum(cur(), fp(dchat[k]), n, Ci, dl, fpm(dhp)));
+                dHs[k] = at::empty({N, D}, opt);
+                Tensor dWch = at::empty_like(lp(k, L_CH_W));
+                const float* xs[1] = {fp(ls.Hs)}; float* dxs[1] = {fpm(dHs[k])};
+                auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(n, dl, D), dev);
+                SMIN_CK(smin_linear_rows_bwd(cur(), fp(dhp), xs, 1, fp(trk(k, TR_CH)), n, dl, D, dxs, fpm(dWch), nullptr, ws.p, ws.n));
+                acc(dlp(k, L_CH_W), dWch);
+            }
+            // gate: every consumer of hbar_k (clip-mean update, boundary unit, the later layers' running sums) and of f_m (residual; layer 0: the clip-mean chain)
+            wait_stream(curs, side);
+            {
+                std::vector<Tensor> later;
+                for (int64_t kk = k + 1; kk < nl; ++kk) later.push_back(dHs[kk]);
+                std::vector<const float*> dh{fp(dcum), fp(dhbar_b)}, dr{fp(dfm)};
+                Tensor later_sum;
+                if (later.size() <= 2) for (auto& t : later) dh.push_back(fp(t));
+                else { later_sum = sum_list(later); dh.push_back(fp(later_sum)); }
+                if (k == 0) dr.push_back(fp(dcum));
+                Tensor dfm_k = at::empty({N, D}, opt), dfs = at::empty_like(fs);
+                auto ws = scratch((size_t)4 * B * 512 * D + 4096, dev);
+                SMIN_CK(smin_gate_bwd(cur(), dh.data(), i32(dh.size()), dr.data(), i32(dr.size()), fp(ls.fm), fp(fs), ip(row_ptr), n, B, Li, D, fpm(dfm_k), fpm(dfs), ws.p, ws.n));
+                dfs_parts.push_back(dfs);
+                dfm = dfm_k;
+            }
+            dcum_next = dcum; dfb_next = dfb_k;
+        }
+
+        // ---- the tail.  Second stream: word-side operands (0.9 ms of small-grid kernels at ActivityNet size), then the parameter
+        // products; main stream: clip-window / proposal-map gradients, video encoder, the two LSTM layers.
+        HStream tail = (flags & F_OVERLAP_PREP) ? side_stream(dev.index()) : curs;
+        auto mark = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
+        auto await = [](HStream waiter, hipEvent_t e) { TORCH_CHECK(hipStreamWaitEvent(waiter.stream(), e, 0) == hipSuccess, "hipStreamWaitEvent failed"); };
+        hipEvent_t words_done;
+        wait_stream(tail, curs);
+        {
+            StreamScope sc(tail);
+            std::vector<const float*> gp[4], pp;
+            std::vector<float*> dp;
+            for (int64_t k = 0; k < nl; ++k) {
+                gp[0].push_back(fp(dwhat[k])); gp[1].push_back(fp(dshat[k])); gp[2].push_back(fp(dMq[k])); gp[3].push_back(fp(duq[k]));
+                for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) {
+                    pp.push_back(fp(lp(k, which)));
+                    dlp(k, which) = at::empty_like(lp(k, which));
+                    dp.push_back(fpm(dlp(k, which)));
+                }
+            }
+            Tensor dfw = at::empty_like(fw), dfs = at::empty_like(fs);
+            auto ws = scratch(smin_word_prep_bwd_workspace_bytes(i32(nl), B, Nq, D, dl), dev);
+            SMIN_CK(smin_word_prep_bwd(cur(), gp[0].data(), gp[1].data(), gp[2].data(), gp[3].data(), fp(fw), fp(fs), fp(qmf), fp(st.what), fp(st.kb), pp.data(), i32(nl), B, Nq, D,
+                                       dl, fpm(dfw), fpm(dfs), dp.data(), ws.p, ws.n));
+            dfw_parts.push_back(dfw); dfs_parts.push_back(dfs);
+            if (tail != curs) {
+                for (const Tensor* t : {&dwhat, &dshat, &dMq, &duq}) record_stream(*t, tail);
+                record_stream(dfw, curs); record_stream(dfs, curs);
+            }
+            words_done = mark(tail);
+        }
+
+        // ---- clip-window terms of chat, the proposal map, f
+        Tensor df;
+        hipEvent_t weights_done;
+        auto tab = clip_event_table(dev, Ti, Li, Ci);
+        {
+            std::vector<const float*> ptrs;
+            for (int64_t k = 0; k < nl; ++k) ptrs.push_back(fp(dchat[k]));
+            Tensor dg = at::empty({(int64_t)B * T, nl * dl}, opt);
+            auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
+            SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
+                                               tab.second.data_ptr()));
+            dconsts[0] = dchat[0].sum(0);
+            Tensor df1 = at::empty({B, T, D}, opt), dWch_all = at::empty_like(st.Wch_all);
+            const float* xs[1] = {fp(f)}; float* dxs[1] = {fpm(df1)};
+            auto ws2 = scratch(smin_linear_rows_bwd_workspace_bytes(i32(B * T), i32(nl * dl), D), dev);
+            SMIN_CK(smin_linear_rows_bwd(cur(), fp(dg), xs, 1, fp(Wch_allT), i32(B * T), i32(nl * dl), D, dxs, fpm(dWch_all), nullptr, ws2.p, ws2.n));
+            for (int64_t k = 0; k < nl; ++k) acc(dlp(k, L_CH_W), dWch_all.slice(0, k * dl, (k + 1) * dl));
+            weights_done = mark(curs);
+            df = at::empty({B, T, D}, opt);
+            auto ws3 = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
+            SMIN_CK(smin_proposal_map_bwd(cur(), nullptr, fp(dfm), fp(dfb_next), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, D, fpm(df), ws3.p, ws3.n, ip(tab.first),
+                                          tab.second.data_ptr()));
+            df.add_(df1);
+        }
+
+        // ---- parameter products on the second stream: consts_k = b_ch_k + Wch_k bsum_k (bsum_k = sum_{l<k} b_c_l), Pcat_k = [Wch_k Wc_l]_l
+        if (tail != curs) await(tail, weights_done);
+        {
+            StreamScope sc(tail);
+            Tensor bsum;
+            std::vector<Tensor> bsums(nl);
+            for (int64_t k = 0; k < nl; ++k) { bsums[k] = bsum; bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B); }
+            Tensor dbsum_run;                                                       // sum_{k' > l} Wch_k'^T dconst_k'
+            for (int64_t k = nl - 1; k >= 0; --k) {
+                dlp(k, L_CH_B) = dconsts[k];
+                if (dbsum_run.defined()) dlp(k, L_C_B).add_(dbsum_run);           // in place: the buffer was allocated on the main stream and must outlive this launch
+                if (k > 0) {
+                    dlp(k, L_CH_W).addr_(dconsts[k], bsums[k]);
+                    Tensor dbs = at::mv(trk(k, TR_CH), dconsts[k]);
+                    dbsum_run = dbsum_run.defined() ? dbsum_run + dbs : dbs;
+                }
+                for (size_t part = 0; part < dPcat[k].size(); ++part)
+                    for (int64_t l = (int64_t)part * 4; l < std::min<int64_t>((int64_t)part * 4 + 4, k); ++l) {
+                        Tensor dP = dPcat[k][part].slice(1, (l - (int64_t)part * 4) * dl, (l - (int64_t)part * 4 + 1) * dl);
+                        dlp(k, L_CH_W).addmm_(dP, trk(l, TR_C));                   // dWch_k += dP_kl Wc_l^T
+                        dlp(l, L_C_W).addmm_(trk(k, TR_CH), dP);                   // dWc_l  += Wch_k^T dP_kl
+                    }
+            }
+        }
+
+        // ---- backbone on the main stream: video encoder, sentence / word features, the two LSTM layers (models.py:38-83)
+        std::vector<Tensor> dbb(P_LAYER0);
+        {
+            const int Din = i32(st.vx.size(2));
+            const int64_t pe_rows = all[P_PE].size(0);
+            Tensor dfs_video = at::empty_like(fs);
+            dbb[P_VE_W] = at::empty({D, Din}, opt); dbb[P_VE_B] = at::empty({D}, opt);
+            dbb[P_PE] = pe_rows != T ? at::zeros({pe_rows, D}, opt) : at::empty({T, D}, opt);
+            auto ws = scratch(smin_video_encoder_bwd_workspace_bytes(B, Ti, Din, D), dev);
+            SMIN_CK(smin_video_encoder_bwd(cur(), fp(df), fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, fpm(dbb[P_VE_W]), fpm(dbb[P_VE_B]), fpm(dbb[P_PE]),
+                                           fpm(dfs_video), ws.p, ws.n));
+            dfs_parts.push_back(dfs_video);
+            if (tail != curs) await(curs, words_done);
+            Tensor dfs_total = sum_list(dfs_parts), dfw_total = sum_list(dfw_parts);
+            // f_s = [f_w[b, len_b - 1, :H] | f_w[b, 0, H:]] (models.py:60-62)
+            dfw_total.slice(2, 0, H).scatter_add_(1, st.last, dfs_total.slice(1, 0, H).unsqueeze(1));
+            dfw_total.select(1, 0).slice(1, H).add_(dfs_total.slice(1, H));
+            Tensor dH = Nq_in < Nq ? dfw_total.slice(1, 0, Nq_in).contiguous() : dfw_total;
+            for (int layer = 1; layer >= 0; --layer) {
+                LstmState& ls = st.lstm[layer];
+                const int In = i32(ls.x.size(2)), Hh = i32(H);
+                Tensor dX = layer > 0 ? at::empty_like(ls.x) : Tensor();
+                Tensor dWih = at::empty_like(ls.Wih), dbias = at::empty({8 * H}, opt), dWhh = at::empty_like(ls.Whh);
+                auto wsl = scratch(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh), dev);
+                SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
+                                              fpm(dX), fpm(dWih), fpm(dbias), fpm(dWhh), wsl.p, wsl.n));
+                const int64_t H4 = 4 * H;
+                Tensor* o = &dbb[P_LSTM + 8 * layer];
+                Tensor db_f = dbias.slice(0, 0, H4), db_r = dbias.slice(0, H4);
+                o[0] = dWih.slice(0, 0, H4); o[1] = dWhh[0]; o[2] = db_f; o[3] = db_f; o[4] = dWih.slice(0, H4); o[5] = dWhh[1]; o[6] = db_r; o[7] = db_r;
+                dH = dX;
+            }
+        }
+        wait_stream(curs, tail);
+        if (tail != curs) for (auto& t : dprm) record_stream(t, curs);
+
+        variable_list out(N_FIXED + all.size());
+        for (size_t i = 0; i < all.size(); ++i) out[N_FIXED + i] = i < (size_t)P_LAYER0 ? dbb[i] : dprm[i - P_LAYER0];
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- the model
 
 struct Words { Tensor Mq, uq, what, shat; };
 
@@ -598,7 +1134,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
                                                         const Tensor& length_mask, const Tensor& moment_mask, at::TensorList prm, at::IntArrayRef cfg)
 {
     TORCH_CHECK(video_features.is_cuda(), "smin_forward runs on a HIP device only (there is no CPU fallback)");
-    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep]");
+    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core)]");
     const int64_t T = cfg[0], L = cfg[1], C = cfg[2], D = cfg[3], nl = cfg[5], maxq = cfg[6], H = cfg[7];
     const bool overlap_boundary = cfg[8] != 0, overlap_prep = cfg[9] != 0;
     TORCH_CHECK((int64_t)prm.size() == P_LAYER0 + nl * L_COUNT + 8, "smin_forward: expected ", P_LAYER0 + nl * L_COUNT + 8, " parameters, got ", prm.size());
@@ -607,6 +1143,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
     const int64_t B = video_features.size(0), Tn = video_features.size(1), Nq = query_features.size(1);
     auto lp = [&](int64_t k, int which) -> const Tensor& { return prm[P_LAYER0 + k * L_COUNT + which]; };
     const Tensor* loc = &prm[P_LAYER0 + nl * L_COUNT];
+    if (cfg.size() >= 11 && cfg[10] != 0 && !video_features.requires_grad() && !query_features.requires_grad()) {      // the whole model as one node
+        const int64_t flags = (overlap_boundary ? SminCore::F_OVERLAP_BOUNDARY : 0) | (overlap_prep ? SminCore::F_OVERLAP_PREP : 0);
+        auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
+        Tensor psea = out[1];
+        return std::make_tuple(out[0], psea[0], psea[1], psea[2]);
+    }
 
     // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
     Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
@@ -767,7 +1309,7 @@ Tensor smin_loss(const Tensor& pm, const Tensor& ym, const Tensor& sm, const Ten
 TORCH_LIBRARY(smin_hip, m)
 {
     // SMIN.forward (reference models.py:367-377): the six forward arguments, the parameters in SMIN._native_params order and
-    // cfg = [T, L, C, D, dl, num_smi_layers, max_query_length, lstm_hidden_size, overlap_boundary, overlap_prep]
+    // cfg = [T, L, C, D, dl, num_smi_layers, max_query_length, lstm_hidden_size, overlap_boundary, overlap_prep, fused_core]
     m.def("smin_forward(Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask, Tensor moment_mask, "
           "Tensor[] params, int[] cfg) -> (Tensor, Tensor, Tensor, Tensor)", &smin_forward);
     // restated loss_fn of the reference's train loop (main.py:110-116), same argument order

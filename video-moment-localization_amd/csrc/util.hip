@@ -183,6 +183,100 @@ extern "C" int smin_unpack_cells(void* stream, const float* packed, const int32_
     return 0;
 }
 
+// ---- small host helpers of the fused step (torch_binding.cpp): many tiny matrices / vectors in one launch each
+namespace smin {
+struct TransposeBatch { const float* src[SMIN_BATCH_MAX]; float* dst[SMIN_BATCH_MAX]; int rows[SMIN_BATCH_MAX], cols[SMIN_BATCH_MAX], tile0[SMIN_BATCH_MAX + 1]; int n; };
+
+// dst[c][r] = src[r][c] for every matrix of the batch; one 32x32 tile per workgroup (256 threads), tiles of all matrices in one grid
+__global__ __launch_bounds__(256)
+void transpose_batch_kernel(TransposeBatch tb)
+{
+    __shared__ float t[32][33];
+    int m = 0;
+    while (m + 1 < tb.n && (int)blockIdx.x >= tb.tile0[m + 1]) ++m;
+    const int rows = tb.rows[m], cols = tb.cols[m], tc = (cols + 31) / 32;
+    const int tile = blockIdx.x - tb.tile0[m], r0 = (tile / tc) * 32, c0 = (tile % tc) * 32;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+    const float* __restrict__ src = tb.src[m];
+    float* __restrict__ dst = tb.dst[m];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + y + 8 * k, c = c0 + x;
+        t[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + y + 8 * k, r = r0 + x;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = t[x][y + 8 * k];
+    }
+}
+
+struct SumList { const float* p[SMIN_BATCH_MAX]; int n; };
+// out[i] = sum_k p[k][i], in list order (deterministic); float4 columns, scalar tail
+template <int NFIX>
+__global__ __launch_bounds__(256)
+void sum_lists_kernel(SumList sl, size_t numel, float* __restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= numel) return;
+    const int n = NFIX ? NFIX : sl.n;
+    if (i + 4 <= numel) {
+        float4 s = ldg4(sl.p[0] + i);
+        if (NFIX) {
+            float4 v[NFIX ? NFIX : 1];
+#pragma unroll
+            for (int k = 1; k < NFIX; ++k) v[k] = ldg4(sl.p[k] + i);
+#pragma unroll
+            for (int k = 1; k < NFIX; ++k) s = f4add(s, v[k]);
+        } else {
+            for (int k = 1; k < n; ++k) s = f4add(s, ldg4(sl.p[k] + i));
+        }
+        stg4(out + i, s);
+    } else {
+        for (size_t j = i; j < numel; ++j) {
+            float s = sl.p[0][j];
+            for (int k = 1; k < n; ++k) s += sl.p[k][j];
+            out[j] = s;
+        }
+    }
+}
+}  // namespace smin
+
+extern "C" int smin_transpose_batch(void* stream, const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols, int n)
+{
+    SMIN_REQUIRE(n >= 0 && n <= SMIN_BATCH_MAX);
+    if (n == 0) return 0;
+    TransposeBatch tb;
+    int tiles = 0;
+    for (int m = 0; m < n; ++m) {
+        SMIN_REQUIRE(rows[m] > 0 && cols[m] > 0);
+        tb.src[m] = src[m]; tb.dst[m] = dst[m]; tb.rows[m] = rows[m]; tb.cols[m] = cols[m]; tb.tile0[m] = tiles;
+        tiles += cdiv(rows[m], 32) * cdiv(cols[m], 32);
+    }
+    tb.tile0[n] = tiles; tb.n = n;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, tb);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_sum_lists(void* stream, const float* const* srcs, int n, size_t numel, float* out)
+{
+    SMIN_REQUIRE(n >= 1 && n <= SMIN_BATCH_MAX);
+    if (numel == 0) return 0;
+    SumList sl;
+    for (int k = 0; k < n; ++k) sl.p[k] = srcs[k];
+    sl.n = n;
+    for (int k = 0; k < n; ++k) SMIN_REQUIRE(((uintptr_t)srcs[k] & 15) == 0);
+    SMIN_REQUIRE(((uintptr_t)out & 15) == 0);
+    const dim3 grid((unsigned)((numel + 1023) / 1024));
+    if (n == 2) hipLaunchKernelGGL(sum_lists_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, sl, numel, out);
+    else if (n == 4) hipLaunchKernelGGL(sum_lists_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, sl, numel, out);
+    else hipLaunchKernelGGL(sum_lists_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, sl, numel, out);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K)
 {
     SMIN_REQUIRE(K % 4 == 0 && N % 4 == 0);

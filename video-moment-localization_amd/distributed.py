@@ -48,14 +48,17 @@ def wrap(model, device=None, bucket_cap_mb=8):
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("SMIN_FORCE_DDP")):
         return model
     changed = {}
-    if dist.get_backend() == "gloo" and getattr(model, "overlap_boundary", False) and device is not None and device.type == "cuda":
+    gloo_on_gpu = dist.get_backend() == "gloo" and device is not None and device.type == "cuda"
+    if gloo_on_gpu and getattr(model, "overlap_boundary", False):
         # gloo stages every bucket through the host and synchronises the streams a gradient touched: with the two-stream
         # step that serialises the whole backward pass (8x slower, measured); RCCL is unaffected
         model.overlap_boundary = changed["overlap_boundary"] = False
-    if getattr(model, "overlap_prep", False):
-        # DDP creates every parameter's gradient accumulator on the stream it is constructed on; parameters that the step
-        # touches only on the second stream then make the main stream wait at each accumulation (measured +0.7 ms over
-        # keeping that work on the main stream; the boundary unit's overlap still pays)
+    one_node = getattr(model, "fused_core", False) and getattr(model, "native_host", False) and not os.environ.get("SMIN_DDP_NO_PREP_OVERLAP")
+    if getattr(model, "overlap_prep", False) and (gloo_on_gpu or not one_node):
+        # node-per-module graph: DDP creates every parameter's gradient accumulator on the stream it is constructed on; parameters
+        # that the step touches only on the second stream then make the main stream wait at each accumulation (measured +0.7 ms
+        # over keeping that work on the main stream; the boundary unit's overlap still pays).  The one-node step hands every
+        # gradient over on the main stream and keeps its second-stream tail under RCCL.
         model.overlap_prep = changed["overlap_prep"] = False
     model.ddp_overrides = changed                      # what wrap() switched off, for the caller to report
     if changed:
