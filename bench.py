@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only")
-    ap.add_argument("--gemm", "--dtype", dest="gemm", default="f32", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--gemm", "--dtype", dest="gemm", default="f32", choices=["f32", "f32e", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (f32 = the reference's, the headline; bf16 = BASELINE.json configs[1])")
     ap.add_argument("--feed", default="resident", choices=["resident", "host"],
                     help="resident (default, the headline): inputs live in HBM; host: every step's batch comes through BatchFeeder "
@@ -169,6 +169,8 @@ def main():
         model.overlap_boundary = False
     if os.environ.get("SMIN_NO_PREP_OVERLAP"):
         model.overlap_prep = False
+    if os.environ.get("SMIN_SYNC_WEIGHTS"):                  # A/B switch: weight gradients on the main stream
+        model.async_weights = False
     if os.environ.get("SMIN_NODE_GRAPH"):                    # A/B switch: one autograd node per module instead of the fused core
         model.fused_core = False
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
@@ -300,7 +302,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_with_adam": None if args.no_optimizer else ms,
             "ms_fwd_bwd": elapsed_fb / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 products, fp32 accumulate)", "bf16": "bf16 (products; fp32 accumulate and storage)"}[args.gemm],
+            "dtype": {"f32": "f32", "f32e": "f32 (emulated on the bf16 matrix cores: exact 3-way split, 6 products, fp32 accumulate)", "bf16x3": "f32 (split-bf16 products, fp32 accumulate)", "bf16": "bf16 (products; fp32 accumulate and storage)"}[args.gemm],
             "data": "synthetic" if args.feed == "resident" else "synthetic, fed from pinned host memory every step (BatchFeeder: async H2D + device-side targets)",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"

@@ -34,12 +34,14 @@ extern "C" {
 #define SMIN_HIP_ABI_VERSION 1
 
 int smin_abi_version(void);
-/* Arithmetic of the dense "NT" contractions (forward maps and input gradients):
+/* Arithmetic of the dense contractions (forward maps, input gradients, weight gradients):
  *   0 (default) exact fp32 on v_mfma_f32_32x32x2_f32;
  *   1 split-bf16: operands split into hi+lo bf16 on the fly, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with
- *     fp32 accumulation (~1e-5 relative on a dot product, 5.3x the fp32 matrix rate).
- *   2 plain bf16: every contraction (forward, input gradients AND weight gradients) rounds its operands to bf16 once and
- *     accumulates in fp32 on v_mfma_f32_32x32x16_bf16 (~4e-3 relative per product; BASELINE.json configs[1]).
+ *     fp32 accumulation (~2^-16 relative per product, ~1e-5 on a dot product);
+ *   2 plain bf16: operands rounded to bf16 once, fp32 accumulation (~4e-3 relative per product; BASELINE.json configs[1]);
+ *   3 fp32 emulated on the bf16 matrix cores: operands split EXACTLY into three bf16 pieces (3 x 8 mantissa bits), six
+ *     products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) accumulated in fp32, smallest first; the three dropped terms
+ *     are <= 2^-26 relative per product, below fp32's own product rounding -- results agree with mode 0 to fp32 rounding.
  * Process-wide; returns 0 or -1 for an unknown mode. */
 int smin_set_gemm_mode(int mode);
 int smin_get_gemm_mode(void);
@@ -158,7 +160,9 @@ int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, con
 /* x1[n][:] = f_b[b][i][:] * f_b[b][j][:]  -- the pair half of the moment unit's left operand (models.py:292-294) */
 int smin_pair_product(void* stream, const float* fb, const int32_t* cells, int N, int L, int D, float* x1);
 /* WcatT [2D][D].  dfcmean [N][D], dfb [B][L][D], dWcat [D][2D], dbcat [D]; the residual gradient
- * d mu / d fm is the identity and is left to the caller (dfm += dmu). */
+ * d mu / d fm is the identity and is left to the caller (dfm += dmu).  Either half may be skipped: dfcmean == dfb == NULL
+ * computes only the weight gradients, dWcat == dbcat == NULL only the input gradients (the halves share nothing but
+ * dmu, so a host may run them on two streams; each call needs its own workspace). */
 int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                          const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                          float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
@@ -240,8 +244,8 @@ int smin_content_attn_bwd(void* stream, const float* dcc, const float* dccmean, 
 /* y[r][:] = [x_0[r] | .. | x_{nseg-1}[r]] W^T + bias + add_rows[r][:] + add_cells[r / C][:]
  * xs: HOST array of nseg <= 4 device pointers, x_s [R][K]; W [O][nseg*K]; y [R][O]; bias, add_rows, add_cells may
  * be NULL.  Backward: dx_s = dy W_s (dxs: HOST array of nseg device pointers, or NULL; WT = W^T [nseg*K][O]),
- * dW [O][nseg*K] = dy^T [x_0 | ..], dbias = colsum(dy) (may be NULL); the gradient of add_rows is dy itself, of
- * add_cells smin_group_sum(dy). */
+ * dW [O][nseg*K] = dy^T [x_0 | ..] (NULL, with dbias NULL, to skip the weight half), dbias = colsum(dy) (may be NULL);
+ * the gradient of add_rows is dy itself, of add_cells smin_group_sum(dy). */
 int smin_linear_rows_fwd(void* stream, const float* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
                          const float* add_cells, int C, int R, int O, int K, float* y);
 size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot);

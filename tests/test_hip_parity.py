@@ -448,6 +448,81 @@ def test_full_size_against_golden_bf16x3(dev, bf16x3, name):
     print("bf16x3", name, "worst grad-norm deviation", worst)
 
 
+# ---------------------------------------------------------------- fp32 emulated on the bf16 matrix cores ("f32e")
+@pytest.fixture()
+def f32e():
+    import models
+    models.vml_amd.set_gemm_mode("f32e")
+    yield
+    models.vml_amd.set_gemm_mode("f32")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 512), (515, 512, 128), (4096, 512, 1024), (37, 20, 16), (300, 64, 2052)])
+def test_gemm_engines_f32e(dev, M, N, K):
+    """Three-way bf16 split, six products, fp32 accumulation: the error against fp64 must sit where the exact fp32 MFMA's does
+    (both are dominated by fp32 accumulation), for the NT engine and -- through the linear-rows weight gradient -- the TN engine."""
+    import models
+    from vml_amd.functional import gemm_nt, LinearRowsFn
+    g = torch.Generator().manual_seed(M + N + K)
+    scale = torch.exp(torch.randn(M, 1, generator=g) * 2)              # rows of very different magnitude: the split is per element
+    a = torch.randn(M, K, generator=g) * scale
+    b = torch.randn(N, K, generator=g)
+    ref = a.double() @ b.double().t()
+    errs = {}
+    for mode in ("f32", "f32e"):
+        models.vml_amd.set_gemm_mode(mode)
+        try:
+            got = gemm_nt(a.to(dev), b.to(dev)).cpu().double()
+            errs[mode] = ((got - ref).abs() / (a.double().abs() @ b.double().abs().t() + 1e-30)).max().item()
+            if K % 4 == 0 and N % 4 == 0:
+                x = a.to(dev).clone().requires_grad_(True)
+                w = b.to(dev).clone().requires_grad_(True)
+                y = LinearRowsFn.apply(w, None, None, None, 1, x)
+                dy = torch.randn(M, N, generator=g).to(dev)
+                y.backward(dy)
+                dw_ref = dy.cpu().double().t() @ a.double()
+                dx_ref = dy.cpu().double() @ b.double()
+                errs[mode + "/dW"] = ((w.grad.cpu().double() - dw_ref).abs() / (dy.cpu().double().abs().t() @ a.double().abs() + 1e-30)).max().item()
+                errs[mode + "/dX"] = ((x.grad.cpu().double() - dx_ref).abs() / (dy.cpu().double().abs() @ b.double().abs() + 1e-30)).max().item()
+        finally:
+            models.vml_amd.set_gemm_mode("f32")
+    print("f32e gemm", (M, N, K), errs)
+    for k, v in errs.items():
+        assert v < 1e-6, (k, v)                                         # componentwise: |err| <= 4e-7 * sum |a||b|  (fp32 unit roundoff 6e-8)
+    for k in [k for k in errs if k.startswith("f32e")]:
+        assert errs[k] <= 4 * errs[k.replace("f32e", "f32")] + 6e-8, (k, errs)
+
+
+@pytest.mark.parametrize("name", ["charades", "anet_t256", "tacos_d500"])
+def test_full_size_against_golden_f32e(dev, f32e, name):
+    """The fp32 golden check at the fp32 mode's own tolerances, with every contraction emulated on the bf16 cores."""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    z = H.load_npz("g5_" + name)
+    T, L, C, D, dl, layers, Din, Nq, Hh = H.FULL[name]
+    B, seed = int(z["cfg"][-2]), int(z["cfg"][-1])
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.3)
+    m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+    batch = O.synthetic_batch(B, T, L, Nq, Din, seed=seed)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    pm, ps, pe, pa = m(*H.model_inputs(b))
+    for k, v in (("pm", pm), ("ps", ps), ("pe", pe), ("pa", pa)):
+        err = (v.detach().cpu() - torch.from_numpy(z["out/" + k])).abs().max().item()
+        print("f32e", name, k, "max abs err", err)
+        assert err < 5e-6, (k, err)               # fp32 mode: 6e-8 .. 8e-7; its test allows 1e-4, north_star 1e-3
+    loss = loss_fn(pm, b["ym"], b["sm"], b["moment_mask"], ps, b["ys"], b["ss"], pe, b["ye"], b["se"], pa, b["ya"], b["length_mask"])
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    norms = dict(zip([str(s) for s in z["grad_names"]], z["grad_norms"]))
+    for k, p in m.named_parameters():
+        got = p.grad.double().norm().item()
+        assert abs(got - norms[k]) <= 2e-3 * norms[k] + 1e-7, (k, got, norms[k])
+    for k in [f for f in z.files if f.startswith("grad/")]:
+        ref = torch.from_numpy(z[k])
+        got = dict(m.named_parameters())[k[5:]].grad.cpu()
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-7, k
+
+
 # ---------------------------------------------------------------- plain bf16 contraction mode (BASELINE.json configs[1])
 @pytest.fixture()
 def bf16_mode():

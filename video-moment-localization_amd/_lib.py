@@ -188,13 +188,14 @@ def prof_read(cap=1 << 16):
     return out
 
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "f32e": 3}
 
 
 def set_gemm_mode(mode):
-    """Arithmetic of the dense contractions: "f32" (exact fp32 MFMA, default), "bf16x3" (forward / input gradients as split-bf16
-    on the bf16 matrix cores, fp32 accumulate; ~1e-5 relative) or "bf16" (every contraction, weight gradients included, with
-    operands rounded to bf16 once and fp32 accumulation; ~4e-3 relative per product -- BASELINE.json configs[1])."""
+    """Arithmetic of the dense contractions (forward, input gradients, weight gradients): "f32" (exact fp32 MFMA, default),
+    "f32e" (fp32 emulated on the bf16 matrix cores: exact three-way bf16 split of each operand, six products, fp32 accumulation --
+    agrees with "f32" to fp32 rounding), "bf16x3" (two-way split, three products; ~1e-5 relative) or "bf16" (operands rounded to
+    bf16 once; ~4e-3 relative per product -- BASELINE.json configs[1])."""
     check(load().smin_set_gemm_mode(GEMM_MODES[mode]), "smin_set_gemm_mode")
 
 

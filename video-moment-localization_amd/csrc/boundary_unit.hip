@@ -266,14 +266,26 @@ struct EpAccum {                    // out += acc
     }
 };
 
-__global__ void rows_reduce_kernel(const float* __restrict__ partial, int L, int D, float* __restrict__ out)
+// out[b][:] = sum_i partial[b][i][:]; grid (D / 256, B), 256 threads = 64 float4 columns x 4 row groups, fixed-order combine through LDS
+__global__ __launch_bounds__(256)
+void rows_reduce_kernel(const float* __restrict__ partial, int L, int D, float* __restrict__ out)
 {
-    const int b = blockIdx.y;
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
-    float s = 0.f;
-    for (int i = 0; i < L; ++i) s += partial[((size_t)b * L + i) * D + d];
-    out[(size_t)b * D + d] = s;
+    __shared__ float4 sh[4][64];
+    const int b = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int d = (blockIdx.x * 64 + c) * 4;
+    float4 s = f4zero();
+    if (d < D) {
+        const float* p = partial + (size_t)b * L * D + d;
+        int i = g;
+        for (; i + 12 < L; i += 16) {                                   // four rows in flight per thread
+            const float4 a0 = ldg4(p + (size_t)i * D), a1 = ldg4(p + (size_t)(i + 4) * D), a2 = ldg4(p + (size_t)(i + 8) * D), a3 = ldg4(p + (size_t)(i + 12) * D);
+            s = f4add(f4add(f4add(f4add(s, a0), a1), a2), a3);
+        }
+        for (; i < L; i += 4) s = f4add(s, ldg4(p + (size_t)i * D));
+    }
+    sh[g][c] = s;
+    __syncthreads();
+    if (g == 0 && d < D) stg4(out + (size_t)b * D + d, f4add(f4add(sh[0][c], sh[1][c]), f4add(sh[2][c], sh[3][c])));
 }
 
 }  // namespace smin
@@ -371,7 +383,7 @@ extern "C" int smin_boundary_unit_bwd(void* stream, const float* dout, const flo
     hipLaunchKernelGGL(boundary_self_bwd_cols_kernel, dim3(L, B), dim3(256), sizeof(float) * (2 * L + 64), st, dout, draw, A, bqv, baq, fb, fs, fw, Kb,
                        P, qmask, lmask, L, Nq, D, scale, dfb, dbaq_lm, dfs_part, dQK, dQb);
     SMIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, dfs_part, L, D, dfs);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, dfs_part, L, D, dfs);   // D % 4 == 0
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(boundary_words_bwd_kernel, dim3(Nq, B), dim3(256), 0, st, dQK, P, Qb, dbaq_lm, L, Nq, D, dKb, dfw);
     SMIN_LAUNCH_CHECK();

@@ -291,40 +291,65 @@ void gemm_nt_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m,
     }
 }
 
-// ------------------------------------------------------------------ NT kernel, split-bf16 ("bf16x3") variant
-// fp32 operands are split on the fly into hi = bf16(x) and lo = bf16(x - hi) and every 16-deep block is accumulated
-// as  hi*hi + hi*lo + lo*hi  with v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped lo*lo term and the
-// residual of the split are ~2^-16 relative per product, i.e. ~1e-5 on a dot product instead of fp32's ~1e-7, at
-// 16/3 = 5.3x the matrix rate of the exact fp32 MFMA.  Same tiling, loaders and epilogues as gemm_nt_body.
+// ------------------------------------------------------------------ NT kernel on the bf16 matrix cores
+// fp32 operands are split on the fly into bf16 pieces and every 16-deep block is accumulated with
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the rate of the fp32 MFMA).  NPROD selects the arithmetic:
+//   6  x = hi + mid + lo EXACTLY (3 x 8 mantissa bits), products  lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, smallest first.
+//      The three dropped cross terms are <= 2^-26 relative per product, below fp32's own product rounding (2^-24): an fp32
+//      contraction computed on the bf16 cores ("f32e" mode; the same idea as library BF16x9 fp32 emulation, minus the three
+//      terms that cannot reach an fp32 result), at 16/6 = 2.7x the fp32 matrix rate;
+//   3  x ~ hi + lo, products  lo*hi + hi*lo + hi*hi: ~2^-16 relative per product (~1e-5 on a dot product), 5.3x the fp32 rate;
+//   1  plain bf16: operands rounded once, one product, ~4e-3 relative per product.
+// Same tiling, loaders and epilogues as gemm_nt_body.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo)
+template <int NIMG>
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2 (&out)[NIMG])
 {
     const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], l[4];
+    unsigned short pc[NIMG][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const __bf16 hb = (__bf16)x[q];
-        h[q] = __builtin_bit_cast(unsigned short, hb);
-        l[q] = __builtin_bit_cast(unsigned short, (__bf16)(x[q] - (float)hb));
+        float r = x[q];
+#pragma unroll
+        for (int i = 0; i < NIMG; ++i) {
+            const __bf16 b = (__bf16)r;
+            pc[i][q] = __builtin_bit_cast(unsigned short, b);
+            r -= (float)b;                                          // exact: the difference of a float and its leading bits
+        }
     }
-    hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+#pragma unroll
+    for (int i = 0; i < NIMG; ++i)
+        out[i] = make_uint2((unsigned)pc[i][0] | ((unsigned)pc[i][1] << 16), (unsigned)pc[i][2] | ((unsigned)pc[i][3] << 16));
 }
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// acc += a * b over the pieces, smallest terms first
+template <int NPROD, int NIMG>
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[NIMG], const bf16x8 (&b)[NIMG], f32x16 c)
+{
+    if constexpr (NPROD == 6) {
+        c = mfma_bf16(a[2], b[0], c);
+        c = mfma_bf16(a[0], b[2], c);
+        c = mfma_bf16(a[1], b[1], c);
+    }
+    if constexpr (NPROD >= 3) {
+        c = mfma_bf16(a[1], b[0], c);
+        c = mfma_bf16(a[0], b[1], c);
+    }
+    return mfma_bf16(a[0], b[0], c);
+}
+constexpr int split_images(int nprod) { return nprod == 6 ? 3 : (nprod == 3 ? 2 : 1); }
 
-// NPROD = 3: the split form above.  NPROD = 1: plain bf16 -- operands rounded to bf16 once, one product per block, fp32
-// accumulate ("bf16" mode of smin_set_gemm_mode: ~4e-3 relative per product, 16x the fp32 matrix rate; the contraction is
-// then bound by its fp32 operand traffic, not by the matrix pipe).
 template <int NPROD, bool MINI, bool KFULL, class AM, class BM_, class EP>
 __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const BM_& bm, const EP& ep, int M, int N, int K,
                                                 int row_base, int col_base)
 {
-    // LDS: four bf16 images per buffer (A_hi, A_lo, B_hi, B_lo), rows of 16 k-values padded to 24 (48 B: the 16-byte
-    // fragment reads of 16 consecutive rows fall on 16 different slots).  2 buffers x 4 x 128 x 48 B = 49,152 B.
-    constexpr int BM = 128, BN = 128, BK = 16, RS = 24, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP, IMG = BM * RS;
+    // LDS: NIMG bf16 images per operand and buffer, rows of 16 k-values padded to 24 (48 B: the 16-byte fragment reads of
+    // 16 consecutive rows fall on 16 different slots).  2 buffers x 2 NIMG x 128 x 48 B = 24,576 / 49,152 / 73,728 B.
+    constexpr int NIMG = split_images(NPROD);
+    constexpr int BM = 128, BK = 16, RS = 24, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP, IMG = BM * RS, BUF = 2 * NIMG * IMG;
     unsigned short* lds = reinterpret_cast<unsigned short*>(smem);
     const int tile_rows = MINI ? 32 : BM;
     const int t = threadIdx.x, lr = t / KQ, kq = (t % KQ) * 4;
@@ -348,7 +373,7 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // Two register stages: the loads of tile kt+3 are issued while tile kt is computed and are consumed two
-    // iterations later -- one iteration of this kernel (12 bf16 MFMAs per wave) is far shorter than an HBM round trip.
+    // iterations later -- one iteration of this kernel is far shorter than an HBM round trip.
     struct Stage { float4 a[NP], b[NP]; };
     const int nk = (K + BK - 1) / BK;
     auto g_load = [&](Stage& st, int kt) {
@@ -364,43 +389,35 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
         }
     };
     auto s_store = [&](const Stage& st, int buf) {
-        unsigned short* base = lds + buf * 4 * IMG;
+        unsigned short* base = lds + buf * BUF;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            uint2 hi, lo;
+            uint2 pc[NIMG];
             const int o = (lr + RPP * p) * RS + kq;
-            split_bf16x4(st.a[p], hi, lo);
-            *reinterpret_cast<uint2*>(base + o) = hi;
-            if (NPROD == 3) *reinterpret_cast<uint2*>(base + IMG + o) = lo;
-            split_bf16x4(st.b[p], hi, lo);
-            *reinterpret_cast<uint2*>(base + 2 * IMG + o) = hi;
-            if (NPROD == 3) *reinterpret_cast<uint2*>(base + 3 * IMG + o) = lo;
+            split_bf16x4<NIMG>(st.a[p], pc);
+#pragma unroll
+            for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(base + i * IMG + o) = pc[i];
+            split_bf16x4<NIMG>(st.b[p], pc);
+#pragma unroll
+            for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(base + (NIMG + i) * IMG + o) = pc[i];
         }
     };
     auto compute = [&](int cur) {
-        const unsigned short* base = lds + cur * 4 * IMG;
+        const unsigned short* base = lds + cur * BUF;
         const unsigned short* ab = base + (wrow + l31) * RS + 8 * h;          // lane (row, h) holds k = 8h .. 8h+7
-        const unsigned short* bb = base + 2 * IMG + (wcol + l31) * RS + 8 * h;
-        bf16x8 ah[NMI], al[NMI], bh[NMI], bl[NMI];
-#pragma unroll
-        for (int i = 0; i < NMI; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * RS);
-            bh[i] = *reinterpret_cast<const bf16x8*>(bb + i * 32 * RS);
-            if (NPROD == 3) {
-                al[i] = *reinterpret_cast<const bf16x8*>(ab + IMG + i * 32 * RS);
-                bl[i] = *reinterpret_cast<const bf16x8*>(bb + IMG + i * 32 * RS);
-            }
-        }
+        const unsigned short* bb = base + NIMG * IMG + (wcol + l31) * RS + 8 * h;
+        bf16x8 af[NMI][NIMG], bf[NMI][NIMG];
 #pragma unroll
         for (int i = 0; i < NMI; ++i)
 #pragma unroll
-            for (int j = 0; j < NMI; ++j) {
-                if (NPROD == 3) {
-                    acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
-                }
-                acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+            for (int q = 0; q < NIMG; ++q) {
+                af[i][q] = *reinterpret_cast<const bf16x8*>(ab + q * IMG + i * 32 * RS);
+                bf[i][q] = *reinterpret_cast<const bf16x8*>(bb + q * IMG + i * 32 * RS);
             }
+#pragma unroll
+        for (int i = 0; i < NMI; ++i)
+#pragma unroll
+            for (int j = 0; j < NMI; ++j) acc[i][j] = mfma_split<NPROD, NIMG>(af[i], bf[j], acc[i][j]);
     };
 
     Stage s0, s1;
@@ -437,10 +454,11 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
 }
 
 template <int NPROD, bool KFULL, class AM, class BM_, class EP>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, NPROD == 6 ? 2 : 3)
 void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m, int tiles_n, int main_blocks)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 4 * 128 * 24 / 2];      // 49,152 B
+    constexpr int LDS_FLOATS = 2 * 2 * split_images(NPROD) * 128 * 24 / 2;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS < 4 * 32 * GEMM_LDW ? 4 * 32 * GEMM_LDW : LDS_FLOATS];
     if ((int)blockIdx.x < main_blocks) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
@@ -452,8 +470,8 @@ void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles
     }
 }
 
-// 0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3) for the NT contractions, 2 = plain bf16 products with fp32
-// accumulation for every contraction (NT and TN); set by smin_set_gemm_mode()
+// 0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3), 2 = plain bf16 products, 3 = fp32 emulated on the bf16 cores
+// (3-way split, 6 products); every contraction (NT and TN); set by smin_set_gemm_mode()
 extern int g_gemm_mode;
 
 constexpr int GEMM_SLOTS = 768;         // resident workgroups: 256 CUs x 3 (40 KB LDS, <= 168 VGPRs each)
@@ -473,20 +491,22 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
     const int rem_rows = M - main_tiles_m * 128;
     const int mini_blocks = rem_rows > 0 ? cdiv(rem_rows, 32) * tiles_n : 0;
     const int main_blocks = cdiv(main_tiles_m, 8) * 8 * tiles_n;
+#define SMIN_NT_SPLIT(NPROD)                                                                                                                   \
+    do {                                                                                                                                       \
+        if (K % 16 == 0)                                                                                                                       \
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<NPROD, true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, \
+                               K, main_tiles_m, tiles_n, main_blocks);                                                                         \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((gemm_nt_x3_kernel<NPROD, false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M,   \
+                               N, K, main_tiles_m, tiles_n, main_blocks);                                                                      \
+    } while (0)
     if (g_gemm_mode == 1) {
-        if (K % 16 == 0)
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<3, true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
-                               main_tiles_m, tiles_n, main_blocks);
-        else
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<3, false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
-                               main_tiles_m, tiles_n, main_blocks);
+        SMIN_NT_SPLIT(3);
     } else if (g_gemm_mode == 2) {
-        if (K % 16 == 0)
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<1, true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
-                               main_tiles_m, tiles_n, main_blocks);
-        else
-            hipLaunchKernelGGL((gemm_nt_x3_kernel<1, false, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
-                               main_tiles_m, tiles_n, main_blocks);
+        SMIN_NT_SPLIT(1);
+    } else if (g_gemm_mode == 3) {
+        SMIN_NT_SPLIT(6);
+#undef SMIN_NT_SPLIT
     } else if (K % 16 == 0)
         hipLaunchKernelGGL((gemm_nt_kernel<true, AM, BM_, EP>), dim3(main_blocks + mini_blocks), dim3(256), 0, st, am, bm, ep, M, N, K,
                            main_tiles_m, tiles_n, main_blocks);
@@ -621,19 +641,41 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
 }
 
 
-// ------------------------------------------------------------------ TN kernel, plain bf16 products ("bf16" mode)
-// Same tiling, splits and XCD-aware order as gemm_tn_kernel; the row (contraction) index is the MFMA k index, so the tiles are
-// kept in LDS transposed ([column][32 rows] in bf16, two consecutive rows packed per 32-bit store) and each lane reads its
-// eight consecutive rows with one 16-byte load.  fp32 accumulation; the bias column sums add the bf16-rounded values.
-template <class AM, class BM_, bool BIAS>
-__global__ __launch_bounds__(256, 3)
+// ------------------------------------------------------------------ TN kernel on the bf16 matrix cores
+// Same tiling, splits and XCD-aware order as gemm_tn_kernel.  The row (contraction) index is the MFMA k index while the operands
+// arrive row-major, so a lane needs eight consecutive ROWS of one column: the tiles are kept in LDS as they arrive ([row][128
+// bf16], written with one 8-byte store per float4) and read with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane
+// group reads 4 rows x 16 columns and each lane receives one column).  Rows are 256 B; 16-byte chunk ch of row r sits at chunk
+// ch ^ (((r&3)<<2) | ((r>>2)&3)), which makes both the row-wise stores and the transposed reads conflict-free.
+// NPROD as in gemm_nt_x3_body (1 plain bf16, 3 split, 6 emulated fp32); fp32 accumulation; the bias column sums add the pieces
+// back (exact for NPROD = 6).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tn_img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__device__ __forceinline__ bf16x8 lds_read_tr2(const unsigned char* p0, const unsigned char* p1)
+{
+    typedef __attribute__((address_space(3))) short4v* lptr;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p1));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const short8v v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NPROD, class AM, class BM_, bool BIAS>
+__global__ __launch_bounds__(256, NPROD == 3 ? 3 : 2)          // NPROD = 1 stages 32 rows (eight float4 per thread and stage)
 void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__ bias_slab,
                          int Mrows, int I, int J, int rows_per_split, int tiles_i, int tiles_j, int splits)
 {
-    constexpr int BI = 128, BJ = 128, BK = 32, RS = BK + 8;          // row stride 40 bf16 = 80 B
-    __shared__ __attribute__((aligned(16))) unsigned short tsm[2 * (BI + BJ) * RS];       // 40,960 B
-    unsigned short* As = tsm;
-    unsigned short* Bs = tsm + 2 * BI * RS;
+    constexpr int NIMG = split_images(NPROD);
+    constexpr int BI = 128, BJ = 128, BK = NIMG == 1 ? 32 : 16, NPK = BK / 8;
+    constexpr int TILE = BK * 256;                                       // bytes of one [BK][128] bf16 tile
+    constexpr int IMG = 2 * TILE;                                        // one image: both buffers
+    __shared__ __attribute__((aligned(16))) unsigned char tsm[2 * NIMG * IMG];     // 32,768 / 32,768 / 49,152 B
+    unsigned char* As = tsm;
+    unsigned char* Bs = tsm + NIMG * IMG;
     const int tiles = tiles_i * tiles_j;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int z = (slot / tiles) * 8 + xcd, tile = slot % tiles;
@@ -641,7 +683,7 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
     const int ti = tile % tiles_i, tj = tile / tiles_i;
     const int m_begin = z * rows_per_split;
     const int m_end = min(Mrows, m_begin + rows_per_split);
-    const int t = threadIdx.x, lk = t >> 5, c4 = (t & 31) * 4;          // thread: rows 2lk, 2lk+1 (+16), columns c4 .. c4+3
+    const int t = threadIdx.x, lk = t >> 5, c4 = (t & 31) * 4;          // thread: rows lk + 8p, columns c4 .. c4+3
     const int ia = min(ti * BI + c4, I - 4), jb = min(tj * BJ + c4, J - 4);
     const int wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     f32x16 acc[2][2];
@@ -653,53 +695,77 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum = 0.f;
     const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
-    struct Stage { float4 a[4], b[4]; };
+    struct Stage { float4 a[NPK], b[NPK]; };
     auto g_load = [&](Stage& st, int kt) {
         const int m0 = m_begin + min(kt, max(nk - 1, 0)) * BK;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = m0 + 2 * lk + (p & 1) + 16 * (p >> 1);
+        for (int p = 0; p < NPK; ++p) {
+            const int m = m0 + lk + 8 * p;
             const bool ok = m < m_end;
             const int mc = min(m, Mrows - 1);
             st.a[p] = f4sel(ok, am.at(am.row(mc), ia));
             st.b[p] = f4sel(ok, bm.at(bm.row(mc), jb));
         }
     };
-    auto pack2 = [](float x, float y) {
-        return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
-    };
-    auto s_store = [&](const Stage& st, int buf) {
-        unsigned short* a0 = As + buf * BI * RS + 2 * lk;
-        unsigned short* b0 = Bs + buf * BJ * RS + 2 * lk;
+    // store offsets of this thread's four columns in rows lk + 8p (the swizzle depends on the row)
+    int woff[NPK];
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                             // rows (2lk, 2lk+1) + 16*pp
-            const float4 x0 = st.a[2 * pp], x1 = st.a[2 * pp + 1], y0 = st.b[2 * pp], y1 = st.b[2 * pp + 1];
-            *reinterpret_cast<unsigned*>(a0 + (c4 + 0) * RS + 16 * pp) = pack2(x0.x, x1.x);
-            *reinterpret_cast<unsigned*>(a0 + (c4 + 1) * RS + 16 * pp) = pack2(x0.y, x1.y);
-            *reinterpret_cast<unsigned*>(a0 + (c4 + 2) * RS + 16 * pp) = pack2(x0.z, x1.z);
-            *reinterpret_cast<unsigned*>(a0 + (c4 + 3) * RS + 16 * pp) = pack2(x0.w, x1.w);
-            *reinterpret_cast<unsigned*>(b0 + (c4 + 0) * RS + 16 * pp) = pack2(y0.x, y1.x);
-            *reinterpret_cast<unsigned*>(b0 + (c4 + 1) * RS + 16 * pp) = pack2(y0.y, y1.y);
-            *reinterpret_cast<unsigned*>(b0 + (c4 + 2) * RS + 16 * pp) = pack2(y0.z, y1.z);
-            *reinterpret_cast<unsigned*>(b0 + (c4 + 3) * RS + 16 * pp) = pack2(y0.w, y1.w);
+    for (int p = 0; p < NPK; ++p) woff[p] = tn_img_off(lk + 8 * p, c4 >> 3) + 8 * ((c4 >> 2) & 1);
+    auto s_store = [&](const Stage& st, int buf) {
+#pragma unroll
+        for (int p = 0; p < NPK; ++p) {
+            uint2 pc[NIMG];
+            split_bf16x4<NIMG>(st.a[p], pc);
+#pragma unroll
+            for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(As + i * IMG + buf * TILE + woff[p]) = pc[i];
+            split_bf16x4<NIMG>(st.b[p], pc);
+#pragma unroll
+            for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(Bs + i * IMG + buf * TILE + woff[p]) = pc[i];
         }
     };
-    auto compute = [&](int cur) {
-        const unsigned short* ab = As + cur * BI * RS + (wm * 64 + l31) * RS + 8 * h;
-        const unsigned short* bb = Bs + cur * BJ * RS + (wn * 64 + l31) * RS + 8 * h;
+    // transposed-read addresses: lane 4q+p of a 16-lane group g supplies row q, columns 4p..4p+3 of the group's 4 x 16 block;
+    // group g covers columns 16 (g&1) .. +15 of the 32-column operand and rows 8 (g>>1) + 4u .. +3 of the 16-deep step (u = 0, 1)
+    const int gq = (lane & 15) >> 2, gp = lane & 3, gcb = (lane >> 4) & 1, ghh = lane >> 5;
+    int roff[BK / 16][2][2][2];                                          // [step][operand A/B][mi/ni][u]
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + 16 * s), a1 = *reinterpret_cast<const bf16x8*>(ab + 32 * RS + 16 * s);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bb + 16 * s), b1 = *reinterpret_cast<const bf16x8*>(bb + 32 * RS + 16 * s);
-            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+    for (int sst = 0; sst < BK / 16; ++sst)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = 16 * sst + 8 * ghh + 4 * u + gq;
+                    const int col = (o == 0 ? wm : wn) * 64 + mi * 32 + 16 * gcb + 4 * gp;
+                    roff[sst][o][mi][u] = tn_img_off(row, col >> 3) + 8 * ((col >> 2) & 1);
+                }
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int sst = 0; sst < BK / 16; ++sst) {
+            bf16x8 af[2][NIMG], bf[2][NIMG];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < NIMG; ++q) {
+                    const unsigned char* pa = As + q * IMG + cur * TILE;
+                    const unsigned char* pb = Bs + q * IMG + cur * TILE;
+                    af[i][q] = lds_read_tr2(pa + roff[sst][0][i][0], pa + roff[sst][0][i][1]);
+                    bf[i][q] = lds_read_tr2(pb + roff[sst][1][i][0], pb + roff[sst][1][i][1]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NPROD, NIMG>(af[i], bf[j], acc[i][j]);
         }
         if (BIAS && tj == 0 && t < BI) {
-            const unsigned short* col = As + cur * BI * RS + t * RS;
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) bsum += (float)__builtin_bit_cast(__bf16, col[kk]);
+            for (int kk = 0; kk < BK; ++kk) {
+                const unsigned char* e = As + cur * TILE + tn_img_off(kk, t >> 3) + 2 * (t & 7);
+                float v = 0.f;
+#pragma unroll
+                for (int q = NIMG - 1; q >= 0; --q) v += (float)__builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short*>(e + q * IMG));
+                bsum += v;
+            }
         }
     };
     Stage s0, s1;
@@ -750,13 +816,20 @@ static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, fl
     const int rows_per_split = cdiv(cdiv(Mrows, splits), 32) * 32;
     const int tiles_i = cdiv(I, 128), tiles_j = cdiv(J, 128);
     dim3 grid(cdiv(splits, 8) * 8 * tiles_i * tiles_j);
-    if (g_gemm_mode == 2) {
-        if (bias_slab)
-            hipLaunchKernelGGL((gemm_tn_bf16_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
-                               tiles_i, tiles_j, splits);
-        else
-            hipLaunchKernelGGL((gemm_tn_bf16_kernel<AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
-                               tiles_i, tiles_j, splits);
+    if (g_gemm_mode != 0) {
+#define SMIN_TN_SPLIT(NPROD)                                                                                                                   \
+    do {                                                                                                                                       \
+        if (bias_slab)                                                                                                                         \
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<NPROD, AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J,      \
+                               rows_per_split, tiles_i, tiles_j, splits);                                                                      \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<NPROD, AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J,     \
+                               rows_per_split, tiles_i, tiles_j, splits);                                                                      \
+    } while (0)
+        if (g_gemm_mode == 1) SMIN_TN_SPLIT(3);
+        else if (g_gemm_mode == 2) SMIN_TN_SPLIT(1);
+        else SMIN_TN_SPLIT(6);
+#undef SMIN_TN_SPLIT
         SMIN_LAUNCH_CHECK();
         return 0;
     }

@@ -108,11 +108,12 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
     SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && nseg >= 1 && nseg <= 4);
     const int Kt = nseg * K;
     if (R == 0) {
-        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * Kt, st);
-        if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)O, st);
+        if (dW) (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * Kt, st);
+        if (dW && dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)O, st);
         return 0;
     }
     SMIN_REQUIRE(ws_bytes >= smin_linear_rows_bwd_workspace_bytes(R, O, Kt));
+    SMIN_REQUIRE(dW != nullptr || dbias == nullptr);                   // the column sum rides on the weight-gradient pass
     int rc;
     if (dxs) {
         if (nseg == 1) {
@@ -125,6 +126,7 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
         }
         if (rc) return rc;
     }
+    if (!dW) return 0;                                                 // input gradients only (the weight half runs elsewhere)
     const int sp = tn_splits(R, O, Kt);
     float* slab = reinterpret_cast<float*>(ws);
     float* bslab = slab + (size_t)sp * O * Kt;

@@ -115,33 +115,39 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
     float* slab = dx1 + (((size_t)N * D + 3) & ~(size_t)3);
     float* bslab = slab + (size_t)sp * D * 2 * D;
     SMIN_REQUIRE((size_t)((bslab + (size_t)sp * D) - w) * sizeof(float) <= ws_bytes);
+    // either half may be skipped (NULL outputs): the two halves share only dmu, so a host can run them on two streams
+    const bool want_in = dfcmean != nullptr || dfb != nullptr, want_w = dWcat != nullptr;
+    SMIN_REQUIRE(!want_in || (dfcmean != nullptr && dfb != nullptr));
+    SMIN_REQUIRE(!want_w || dbcat != nullptr);
     if (N > 0) {
         // dX = (m * dmu) @ Wcat        [N, 2D], contraction over D
         // dWcat[D, 2D] = (m * dmu)^T @ X ; dbcat = colsum(m * dmu)
         // all_valid (mask-driven cell list, m == 1 everywhere): dmu is read as a plain matrix, without the per-row
         // mask lookups the operand loads would otherwise wait for
-        int rc;
-        if (all_valid) {
-            {
-                ProfScope prof(st, SMIN_PROF_MOMENT_DX);
-                rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
-            }
-            if (rc) return rc;
-            ProfScope prof(st, SMIN_PROF_MOMENT_DW);
-            if (x1) rc = launch_gemm_tn(st, PlainMat{dmu, D}, pair_cat(x1, fcmean, D), slab, bslab, N, D, 2 * D, sp);
-            else rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
-        } else {
-            rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
-            if (rc) return rc;
-            rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+        int rc = 0;
+        if (want_in) {
+            ProfScope prof(st, SMIN_PROF_MOMENT_DX);
+            if (all_valid) rc = launch_gemm_nt(st, PlainMat{dmu, D}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
+            else rc = launch_gemm_nt(st, MaskedRowsMat{dmu, D, cells}, PlainMat{WcatT, D}, EpSplitStore{dx1, dfcmean, D, dfcmean_acc}, N, 2 * D, D);
         }
         if (rc) return rc;
-        rc = launch_reduce_slabs2(st, slab, dWcat, D * 2 * D, bslab, dbcat, D, sp); if (rc) return rc;
-    } else {
+        if (want_w) {
+            {
+                ProfScope prof(st, SMIN_PROF_MOMENT_DW);
+                if (!all_valid) rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+                else if (x1) rc = launch_gemm_tn(st, PlainMat{dmu, D}, pair_cat(x1, fcmean, D), slab, bslab, N, D, 2 * D, sp);
+                else rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+            }
+            if (rc) return rc;
+            rc = launch_reduce_slabs2(st, slab, dWcat, D * 2 * D, bslab, dbcat, D, sp); if (rc) return rc;
+        }
+    } else if (want_w) {
         (void)hipMemsetAsync(dWcat, 0, sizeof(float) * (size_t)D * 2 * D, st);
         (void)hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
     }
-    hipLaunchKernelGGL(moment_dfb_kernel, dim3(L, B), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, L, D, dfb);
-    SMIN_LAUNCH_CHECK();
+    if (want_in) {
+        hipLaunchKernelGGL(moment_dfb_kernel, dim3(L, B), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, L, D, dfb);
+        SMIN_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -112,7 +112,7 @@ using namespace smin;
 extern "C" int smin_abi_version(void) { return SMIN_HIP_ABI_VERSION; }
 extern "C" int smin_set_gemm_mode(int mode)
 {
-    if (mode < 0 || mode > 2) return -1;
+    if (mode < 0 || mode > 3) return -1;
     g_gemm_mode = mode;
     return 0;
 }
