@@ -881,6 +881,9 @@ def test_bench_contract_line(dev):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["higher_is_better"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert "workload" in j["config"] and j["value"] > 0
+    # the bf16-core contraction modes are timed beside the headline, never as it; the emulated-fp32 scores sit on the exact ones
+    oa = j["other_arithmetic"]
+    assert set(oa) == {"f32e", "bf16x3"} and oa["f32e"]["max_score_deviation_from_f32"] < 5e-6 and oa["bf16x3"]["max_score_deviation_from_f32"] < 1e-4
 
 
 def test_layout_build_kernels(dev):

@@ -116,8 +116,8 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
     float* bslab = slab + (size_t)sp * D * 2 * D;
     SMIN_REQUIRE((size_t)((bslab + (size_t)sp * D) - w) * sizeof(float) <= ws_bytes);
     // either half may be skipped (NULL outputs): the two halves share only dmu, so a host can run them on two streams
-    const bool want_in = dfcmean != nullptr || dfb != nullptr, want_w = dWcat != nullptr;
-    SMIN_REQUIRE(!want_in || (dfcmean != nullptr && dfb != nullptr));
+    const bool want_in = dfb != nullptr, want_w = dWcat != nullptr;      // (dfcmean [N][D] is legitimately NULL when N == 0)
+    SMIN_REQUIRE(!want_in || N == 0 || dfcmean != nullptr);
     SMIN_REQUIRE(!want_w || dbcat != nullptr);
     if (N > 0) {
         // dX = (m * dmu) @ Wcat        [N, 2D], contraction over D
