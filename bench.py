@@ -174,7 +174,9 @@ def main():
         model.async_weights = False
     if os.environ.get("SMIN_NODE_GRAPH"):                    # A/B switch: one autograd node per module instead of the fused core
         model.fused_core = False
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4)      # main.py:78-83, activitynet.yml lr
+    # main.py:78-83, activitynet.yml lr.  fused=True: torch's single-launch implementation of the same update (the default on a GPU
+    # is the multi-tensor "foreach" form: ~10 launches and ~0.7 ms of host time per step); SMIN_FOREACH_ADAM=1 restores it
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=not os.environ.get("SMIN_FOREACH_ADAM"))
     net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)
     n_valid = int(batch["moment_mask"].sum().item())
@@ -353,7 +355,7 @@ def main():
             "data": "synthetic" if args.feed == "resident" else "synthetic, fed from pinned host memory every step (BatchFeeder: async H2D + device-side targets)",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"
-                                   + ("" if args.no_optimizer else "+Adam") + exchange,
+                                   + ("" if args.no_optimizer else "+Adam (torch fused)" if not os.environ.get("SMIN_FOREACH_ADAM") else "+Adam (torch foreach)") + exchange,
                        "global_batch": total_B, "valid_cells_per_step": n_valid_total,
                        "valid_cells_per_s": n_valid_total / (elapsed / args.steps), "parallelism": f"dp{world}", "dist_backend": backend, "dist_world_size": world_seen,
                        "ddp_overrides": getattr(model, "ddp_overrides", None),
