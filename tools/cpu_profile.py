@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 T, L, C, D, dl, layers, Din, Nq, Hh, B = bench.WORKLOADS[os.environ.get("WL", "activitynet_t256")]
 torch.manual_seed(43)
 model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 batch = bench.make_batch(B, T, L, Nq, Din, seed=1000, device=dev)
 
 

@@ -11,7 +11,7 @@ T, L, C, D, dl, layers, Din, Nq, Hh, B = bench.WORKLOADS[os.environ.get("WL", "a
 torch.manual_seed(43)
 model = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev).to(dev)
 model.fused_core = os.environ.get("FUSED", "1") != "0"
-opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 batch = bench.make_batch(B, T, L, Nq, Din, seed=1000, device=dev)
 acc = [0.0] * 5
 

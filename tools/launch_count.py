@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 ends = []
 for s, e, k in ev:
-    if "multi_tensor_apply" in k:
+    if "multi_tensor_apply" in k or "fused_adam" in k.lower():
         if ends and s - ends[-1] < 2_000_000:
             ends[-1] = e
         else:

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in rows))
-adam = [e for e in ev if "multi_tensor_apply" in e[2]]
+adam = [e for e in ev if ("multi_tensor_apply" in e[2] or "fused_adam" in e[2].lower() or "FusedAdam" in e[2])]
 ends = []
 for s, e, *_ in adam:
     if ends and s - ends[-1] < 2_000_000:

@@ -777,16 +777,11 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
         Tensor bb = at::cat({loc[3], loc[5], loc[7]});
         wait_stream(curs, prep);
-        if (prep != curs) {
-            for (const Tensor* t : {&st.Wch_all, &st.wb, &st.what, &st.kb, &st.Mq, &st.uq, &st.shat}) record_stream(*t, curs);
-            for (int64_t k = 0; k < nl; ++k) {
-                record_stream(st.layer[k].consts, curs); record_stream(st.layer[k].Wcat, curs); record_stream(bcat[k], curs);
-                for (auto& p : st.layer[k].Pcat) record_stream(p, curs);
-            }
-            for (const Tensor* t : {&fw, &fs, &qmf}) record_stream(*t, prep);
-        }
-        if (side != curs)
-            for (const Tensor* t : {&fw, &fs, &qmf, &lmf, &cells, &row_ptr, &cellmap}) record_stream(*t, side);
+        // Tensors cross streams here without recordStream bookkeeping (an event record and queries per tensor and step: ~0.3 ms of
+        // host time).  What makes that safe: (1) every stretch of work on another stream starts with a wait for the main stream and
+        // the main stream waits for every other stream before forward / backward return; (2) no tensor that another stream has
+        // touched is released before that final wait (saved for backward, returned, or held in a function-scope list).  A block
+        // therefore returns to its stream's pool only after all streams have met, and its next user is ordered behind that.
 
         // ---- proposal map (f_m, f_b) and every layer's clip-window term of chat
         Tensor fm = at::empty({N, D}, opt), fb = at::empty({B, L, D}, opt);
@@ -820,7 +815,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                                fp(lp(k, L_BK_W)), fp(lp(k, L_BK_B)), fp(qmf), fp(lmf), fpm(ls.bu), fpm(ls.Qb), fpm(ls.Kb), fpm(ls.P), fpm(ls.baq),
                                                fpm(ls.bqv), fpm(ls.A)));
             }
-            if (side != curs) { record_stream(fb, side); record_stream(ls.hbar, side); }
             // chat_k = clip-window term + [cc_0 | ..] Pcat^T + const_k + (Hs Wch^T per cell)
             Tensor chat = pgs[k];
             ls.Hs = Hs;
@@ -849,7 +843,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
             }
             if (!lastl) Hs = Hs.defined() ? Hs + ls.hbar : ls.hbar;
             wait_stream(curs, side);
-            if (side != curs) for (const Tensor* t : {&ls.bu, &ls.Qb, &ls.Kb, &ls.P, &ls.baq, &ls.bqv, &ls.A}) record_stream(*t, curs);
             ls.x1 = at::empty_like(fm);                                            // f_b[i] * f_b[j], kept for the weight gradient
             Tensor mu = at::empty_like(fm);
             SMIN_CK(smin_pair_product(cur(), fp(ls.bu), ip(cells), n, Li, D, fpm(ls.x1)));
@@ -911,7 +904,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
         std::vector<std::vector<Tensor>> PcatT(nl);
         { size_t i = tr_pcat0; for (int64_t k = 0; k < nl; ++k) for (size_t p = 0; p < st.layer[k].Pcat.size(); ++p) PcatT[k].push_back(tr[i++]); }
         const Tensor &Wch_allT = tr[tr.size() - 3], *WihT = &tr[tr.size() - 2];
-        if (side != curs) for (int64_t k = 0; k < nl; ++k) { record_stream(trk(k, TR_BQ), side); record_stream(trk(k, TR_BK), side); }
 
         // ---- Localization
         const Tensor& bu_last = st.layer[nl - 1].bu;
@@ -971,10 +963,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                                fpm(dWq), fpm(dbq), fpm(dWk), fpm(dbk), ws.p, ws.n));
                 dlp(k, L_BQ_W) = dWq; dlp(k, L_BQ_B) = dbq; dlp(k, L_BK_W) = dWk; dlp(k, L_BK_B) = dbk;
                 dfs_parts.push_back(dfs); dfw_parts.push_back(dfw);
-                if (side != curs) {
-                    record_stream(dfb_next, side); record_stream(dfb_mu, side);
-                    for (const Tensor* t : {&dfb_k, &dhbar_b, &dfw, &dfs, &dWq, &dbq, &dWk, &dbk}) record_stream(*t, curs);
-                }
+                keep.push_back(dfb_next); keep.push_back(dfb_mu); keep.push_back(dhbar_b);
             }
             // clip-mean update cum = ccmean Wc^T + b + cumean + hbar: d ccmean, weight gradients; d cumean = d hbar = dcum
             Tensor dccmean = at::empty({N, dl}, opt);
@@ -1082,10 +1071,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
             SMIN_CK(smin_word_prep_bwd(cur(), gp[0].data(), gp[1].data(), gp[2].data(), gp[3].data(), fp(fw), fp(fs), fp(qmf), fp(st.what), fp(st.kb), pp.data(), i32(nl), B, Nq, D,
                                        dl, fpm(dfw), fpm(dfs), dp.data(), ws.p, ws.n));
             dfw_parts.push_back(dfw); dfs_parts.push_back(dfs);
-            if (tail != curs) {
-                for (const Tensor* t : {&dwhat, &dshat, &dMq, &duq}) record_stream(*t, tail);
-                record_stream(dfw, curs); record_stream(dfs, curs);
-            }
             words_done = mark(tail);
         }
 
@@ -1182,7 +1167,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
         wait_stream(curs, tail);
         wait_stream(curs, wstr);
-        if (tail != curs || wstr != curs) for (auto& t : dprm) record_stream(t, curs);
 
         variable_list out(N_FIXED + all.size());
         for (size_t i = 0; i < all.size(); ++i) out[N_FIXED + i] = i < (size_t)P_LAYER0 ? dbb[i] : dprm[i - P_LAYER0];
