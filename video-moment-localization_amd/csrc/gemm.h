@@ -420,24 +420,52 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
             for (int j = 0; j < NMI; ++j) acc[i][j] = mfma_split<NPROD, NIMG>(af[i], bf[j], acc[i][j]);
     };
 
-    Stage s0, s1;
-    g_load(s0, 0);
-    s_store(s0, 0);
-    g_load(s0, 1);
-    g_load(s1, 2);
+    // One half-step = the matrix products of the resident tile, the split + LDS store of the next one (already in registers) and
+    // the loads of a later tile into the freed registers.  Written without branches so that it is ONE scheduling region, and the
+    // scheduler is told to issue the split's vector instructions between the matrix instructions (a 32x32x16 MFMA occupies the
+    // matrix pipe for 32 cycles during which the wave would otherwise sit idle; left alone, hipcc emits all MFMAs first and the
+    // ~120 split instructions after them).
+    // NST register stages: a tile's loads are issued NST half-steps before its store (four stages measured no faster than two:
+    // the operand latency is not what these kernels wait for).
+    constexpr int NST = 2;
+    Stage stg[NST];
+    auto half_step = [&](int cur, Stage& st, int kt_next_load) {
+        compute(cur);
+        s_store(st, cur ^ 1);
+        g_load(st, kt_next_load);
+        constexpr int NMFMA = NMI * NMI * NPROD;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NMI * NIMG, 0);          // the fragment reads
+#pragma unroll
+        for (int q = 0; q < NMFMA; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, MINI ? 10 : 5, 0);       // a slice of the split (VALU)
+        }
+    };
+    // invariant at the top of the main loop: buffer 0 holds tile kt, stage (j % NST) holds tile kt + j for j = 1 .. NST
+    g_load(stg[0], 0);
+    s_store(stg[0], 0);
+#pragma unroll
+    for (int j = 1; j <= NST; ++j) g_load(stg[j % NST], j);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        compute(0);                                                // tile kt
-        if (kt + 1 < nk) s_store(s0, 1);                           // tile kt+1
-        g_load(s0, kt + 3);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            compute(1);                                            // tile kt+1
-            if (kt + 2 < nk) s_store(s1, 0);                       // tile kt+2
-            g_load(s1, kt + 4);
+    int kt = 0;
+    for (; kt + NST < nk; kt += NST) {                              // tiles kt+1 .. kt+NST exist: no conditions inside
+#pragma unroll
+        for (int hs = 0; hs < NST; ++hs) {
+            half_step(hs & 1, stg[(hs + 1) % NST], kt + hs + 1 + NST);   // tile kt+hs; stores kt+hs+1, reloads its stage
             __syncthreads();
         }
     }
+#pragma unroll
+    for (int hs = 0; hs < NST; ++hs) {                             // the last 1 .. NST tiles
+        if (kt + hs < nk) {
+            compute(hs & 1);
+            if (kt + hs + 1 < nk) {
+                s_store(stg[(hs + 1) % NST], (hs + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();                                               // the accumulator staging below reuses the operand buffers
 
     float* Ws = smem + wave * (32 * GEMM_LDW);
 #pragma unroll
