@@ -796,19 +796,36 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
             }
         }
     };
+    // as in gemm_nt_x3_body: branch-free half-steps, the split's vector instructions issued between the matrix instructions
+    auto half_step = [&](int cur, Stage& st, int kt_next_load) {
+        compute(cur);
+        s_store(st, cur ^ 1);
+        g_load(st, kt_next_load);
+        if (!(BIAS)) {                                               // (the bias variant's column sums are vector work of their own)
+            constexpr int NMFMA = 4 * NPROD * (BK / 16);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+    };
     Stage s0, s1;
     if (nk > 0) { g_load(s0, 0); s_store(s0, 0); g_load(s0, 1); g_load(s1, 2); }
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        compute(0);
-        if (kt + 1 < nk) s_store(s0, 1);
-        g_load(s0, kt + 3);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        half_step(0, s0, kt + 3);
         __syncthreads();
+        half_step(1, s1, kt + 4);
+        __syncthreads();
+    }
+    if (kt < nk) {
+        compute(0);
         if (kt + 1 < nk) {
-            compute(1);
-            if (kt + 2 < nk) s_store(s1, 0);
-            g_load(s1, kt + 4);
+            s_store(s0, 1);
             __syncthreads();
+            compute(1);
         }
     }
     float* out = slab + (size_t)z * I * J;
