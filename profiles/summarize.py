@@ -5,6 +5,9 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+once = [r for r in rows if "loss_fwd_kernel" in r["Name"]]          # launched once per step: the step count of the whole run
+if once:
+    steps = float(once[0]["Calls"])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"# total kernel time {tot/1e6:.3f} ms over {steps:g} steps = {tot/1e6/steps:.3f} ms/step")
 print(f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
