@@ -266,26 +266,29 @@ struct EpAccum {                    // out += acc
     }
 };
 
-// out[b][:] = sum_i partial[b][i][:]; grid (D / 256, B), 256 threads = 64 float4 columns x 4 row groups, fixed-order combine through LDS
+// out[b][s][:] = sum over the rows of slice s of partial[b][i][:]; grid (D / 256, slices, B), 256 threads = 64 float4 columns x 4
+// row groups, fixed-order combine through LDS.  Long maps (L = 512) are reduced in two passes of this kernel: 32 workgroups
+// walking 512 rows each took 4.3 ms per call in the long-video regime.
 __global__ __launch_bounds__(256)
-void rows_reduce_kernel(const float* __restrict__ partial, int L, int D, float* __restrict__ out)
+void rows_reduce_kernel(const float* __restrict__ partial, int L, int rows_per_slice, int D, float* __restrict__ out)
 {
     __shared__ float4 sh[4][64];
-    const int b = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int b = blockIdx.z, sl = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int d = (blockIdx.x * 64 + c) * 4;
+    const int r0 = sl * rows_per_slice, r1 = min(L, r0 + rows_per_slice);
     float4 s = f4zero();
     if (d < D) {
         const float* p = partial + (size_t)b * L * D + d;
-        int i = g;
-        for (; i + 12 < L; i += 16) {                                   // four rows in flight per thread
+        int i = r0 + g;
+        for (; i + 12 < r1; i += 16) {                                  // four rows in flight per thread
             const float4 a0 = ldg4(p + (size_t)i * D), a1 = ldg4(p + (size_t)(i + 4) * D), a2 = ldg4(p + (size_t)(i + 8) * D), a3 = ldg4(p + (size_t)(i + 12) * D);
             s = f4add(f4add(f4add(f4add(s, a0), a1), a2), a3);
         }
-        for (; i < L; i += 4) s = f4add(s, ldg4(p + (size_t)i * D));
+        for (; i < r1; i += 4) s = f4add(s, ldg4(p + (size_t)i * D));
     }
     sh[g][c] = s;
     __syncthreads();
-    if (g == 0 && d < D) stg4(out + (size_t)b * D + d, f4add(f4add(sh[0][c], sh[1][c]), f4add(sh[2][c], sh[3][c])));
+    if (g == 0 && d < D) stg4(out + ((size_t)b * gridDim.y + sl) * D + d, f4add(f4add(sh[0][c], sh[1][c]), f4add(sh[2][c], sh[3][c])));
 }
 
 }  // namespace smin
@@ -383,7 +386,17 @@ extern "C" int smin_boundary_unit_bwd(void* stream, const float* dout, const flo
     hipLaunchKernelGGL(boundary_self_bwd_cols_kernel, dim3(L, B), dim3(256), sizeof(float) * (2 * L + 64), st, dout, draw, A, bqv, baq, fb, fs, fw, Kb,
                        P, qmask, lmask, L, Nq, D, scale, dfb, dbaq_lm, dfs_part, dQK, dQb);
     SMIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, dfs_part, L, D, dfs);   // D % 4 == 0
+    {
+        const int slices = L > 96 ? cdiv(L, 32) : 1;                    // D % 4 == 0
+        if (slices == 1) {
+            hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), 1, B), dim3(256), 0, st, dfs_part, L, L, D, dfs);
+        } else {
+            float* mid = draw;                                          // [B][slices][D] <= [B][L][L] (D <= 2048 < 32 L); draw was consumed by the kernel above
+            hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), slices, B), dim3(256), 0, st, dfs_part, L, 32, D, mid);
+            SMIN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(D, 256), 1, B), dim3(256), 0, st, mid, slices, slices, D, dfs);
+        }
+    }
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(boundary_words_bwd_kernel, dim3(Nq, B), dim3(256), 0, st, dQK, P, Qb, dbaq_lm, L, Nq, D, dKb, dfw);
     SMIN_LAUNCH_CHECK();
