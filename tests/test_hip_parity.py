@@ -835,6 +835,71 @@ def test_gate_gradient_lists_and_pair_product(dev):
     assert (mu_a.double() - ref).abs().max().item() < 1e-4 and (mu_b.double() - ref).abs().max().item() < 1e-4
 
 
+def test_step_helpers_through_the_c_abi(dev):
+    """The entry points the one-node step added: batched transposes, list sums, and the two halves of the backward contractions
+    run separately (as the step does on two streams) against the combined call -- bit for bit."""
+    import ctypes
+    import models
+    from vml_amd._lib import call, ptr, stream
+    lib = models.vml_amd._lib.load()
+    g = torch.Generator().manual_seed(3)
+    # smin_transpose_batch: odd shapes, more than one 32x32 tile, 33 matrices need two calls (SMIN_BATCH_MAX = 32)
+    shapes = [(128, 512), (512, 128), (37, 5), (1, 70), (64, 64), (33, 129)] + [(8, 12)] * 26
+    mats = [torch.randn(r, c, generator=g).to(dev) for r, c in shapes]
+    outs = [torch.empty(c, r, device=dev) for r, c in shapes]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    iarr = lambda v: (ctypes.c_int32 * len(v))(*v)
+    call("smin_transpose_batch", stream(), arr(mats), arr(outs), iarr([s[0] for s in shapes]), iarr([s[1] for s in shapes]), len(mats))
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.t().contiguous())
+    assert lib.smin_transpose_batch(stream(), arr(mats + mats[:1]), arr(outs + outs[:1]), iarr([1] * 33), iarr([1] * 33), 33) < 0      # rejected, not truncated
+    # smin_sum_lists: list order is the summation order
+    for n, numel in [(2, 4096), (4, 1000), (7, 13), (3, 5 * 64 * 20)]:
+        ts = [torch.randn(numel, generator=g).to(dev) for _ in range(n)]
+        out = torch.empty(numel, device=dev)
+        call("smin_sum_lists", stream(), arr(ts), n, numel, ptr(out))
+        ref = ts[0].clone()
+        for t in ts[1:]:
+            ref = ref + t
+        assert torch.equal(out, ref), (n, numel)
+    # halves of the moment-unit backward and of the linear-rows backward
+    B, L, D = 3, 12, 64
+    mm = torch.triu(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0).repeat(B, 1, 1)
+    mm[2, :, 9:] = False
+    lay = models.vml_amd.CellLayout.from_mask(mm.to(dev))
+    N = lay.N
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dmu, fcm, fb, x1, acc = r(N, D), r(N, D), r(B, L, D), r(N, D), r(N, D)
+    WT = (r(2 * D, D) * 0.1).contiguous()
+    nb = lib.smin_workspace_bytes(N, B, 4, D, 4, 1)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+
+    def mu_bwd(want_in, want_w):
+        dfc, dfb, dW, db = torch.full((N, D), 7.0, device=dev), torch.full((B, L, D), 7.0, device=dev), torch.full((D, 2 * D), 7.0, device=dev), torch.full((D,), 7.0, device=dev)
+        call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D, ptr(WT),
+             ptr(dfc) if want_in else None, ptr(dfb) if want_in else None, ptr(dW) if want_w else None, ptr(db) if want_w else None, ptr(ws), ws.numel(), 1,
+             ptr(acc) if want_in else None, ptr(x1))
+        return dfc, dfb, dW, db
+    full, ins, wts = mu_bwd(True, True), mu_bwd(True, False), mu_bwd(False, True)
+    assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])
+    assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0          # the skipped half's outputs are untouched
+    R, K, O = 150, 32, 48
+    dy, xa, xb = r(R, O), r(R, K), r(R, K)
+    WTl = r(2 * K, O)
+    nbl = lib.smin_linear_rows_bwd_workspace_bytes(R, O, 2 * K)
+    wsl = torch.empty(nbl + 64, dtype=torch.uint8, device=dev)
+
+    def lr_bwd(want_in, want_w):
+        dxa, dxb, dW, db = torch.full((R, K), 7.0, device=dev), torch.full((R, K), 7.0, device=dev), torch.full((O, 2 * K), 7.0, device=dev), torch.full((O,), 7.0, device=dev)
+        call("smin_linear_rows_bwd", stream(), ptr(dy), arr([xa, xb]), 2, ptr(WTl), R, O, K, arr([dxa, dxb]) if want_in else None, ptr(dW) if want_w else None,
+             ptr(db) if want_w else None, ptr(wsl), wsl.numel())
+        return dxa, dxb, dW, db
+    full, ins, wts = lr_bwd(True, True), lr_bwd(True, False), lr_bwd(False, True)
+    assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])
+    assert (full[2].double() - dy.double().t() @ torch.cat([xa, xb], 1).double()).abs().max().item() < 1e-3
+    assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
+
+
 def test_degenerate_samples_and_empty_batch(dev):
     """A sample with a single valid snippet, a sample with none, inference under no_grad, and a batch without any valid
     cell (N = 0) with its backward -- the edge cases of the packed layout."""
