@@ -68,6 +68,22 @@ __device__ __forceinline__ float block_dot_row(const float* __restrict__ a, cons
     return wave_sum(s);
 }
 
+// four dot products of one row with four others at once: the four rows' loads are in flight together (one dot per trip left a
+// wave with one L2 round trip per score)
+__device__ __forceinline__ float4 block_dot_row4(const float* __restrict__ a, const float* __restrict__ b0, const float* __restrict__ b1,
+                                                 const float* __restrict__ b2, const float* __restrict__ b3, int D, int lane)
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 x = ldg4(a + d), y0 = ldg4(b0 + d), y1 = ldg4(b1 + d), y2 = ldg4(b2 + d), y3 = ldg4(b3 + d);
+        s0 = fmaf(x.x, y0.x, s0); s0 = fmaf(x.y, y0.y, s0); s0 = fmaf(x.z, y0.z, s0); s0 = fmaf(x.w, y0.w, s0);
+        s1 = fmaf(x.x, y1.x, s1); s1 = fmaf(x.y, y1.y, s1); s1 = fmaf(x.z, y1.z, s1); s1 = fmaf(x.w, y1.w, s1);
+        s2 = fmaf(x.x, y2.x, s2); s2 = fmaf(x.y, y2.y, s2); s2 = fmaf(x.z, y2.z, s2); s2 = fmaf(x.w, y2.w, s2);
+        s3 = fmaf(x.x, y3.x, s3); s3 = fmaf(x.y, y3.y, s3); s3 = fmaf(x.z, y3.z, s3); s3 = fmaf(x.w, y3.w, s3);
+    }
+    return make_float4(wave_sum(s0), wave_sum(s1), wave_sum(s2), wave_sum(s3));
+}
+
 // softmax over n entries of sv[] (LDS) in place by wave 0; entries must already be masked
 __device__ __forceinline__ void block_softmax(float* sv, int n, int t)
 {
@@ -94,11 +110,14 @@ void boundary_rows_fwd_kernel(const float* __restrict__ Qb, const float* __restr
     __shared__ float sv[64];
     const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const size_t r = (size_t)b * L + i;
-    for (int w = wave; w < Nq; w += 4) {
-        const float d = block_dot_row(Qb + r * D, Kb + ((size_t)b * Nq + w) * D, D, lane);
-        if (lane == 0) {
-            const float qm = qmask[(size_t)b * Nq + w];
-            sv[w] = qm == 0.f ? -1e9f : d * scale * qm;                // models.py:141-148
+    for (int w0 = wave * 4; w0 < Nq; w0 += 16) {
+        const float* kb = Kb + (size_t)b * Nq * D;
+        const float4 d4 = block_dot_row4(Qb + r * D, kb + (size_t)w0 * D, kb + (size_t)min(w0 + 1, Nq - 1) * D, kb + (size_t)min(w0 + 2, Nq - 1) * D,
+                                         kb + (size_t)min(w0 + 3, Nq - 1) * D, D, lane);
+        if (lane < 4 && w0 + lane < Nq) {
+            const float d = lane == 0 ? d4.x : lane == 1 ? d4.y : lane == 2 ? d4.z : d4.w;
+            const float qm = qmask[(size_t)b * Nq + w0 + lane];
+            sv[w0 + lane] = qm == 0.f ? -1e9f : d * scale * qm;        // models.py:141-148
         }
     }
     block_softmax(sv, Nq, t);
@@ -120,11 +139,14 @@ void boundary_self_fwd_kernel(const float* __restrict__ bqv, const float* __rest
     extern __shared__ float sz[];                                       // [L]
     const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const size_t r = (size_t)b * L + i;
-    for (int j = wave; j < L; j += 4) {
-        const float d = block_dot_row(bqv + r * D, bqv + ((size_t)b * L + j) * D, D, lane);
-        if (lane == 0) {
-            const float lj = lmask[(size_t)b * L + j];
-            sz[j] = lj == 0.f ? -1e9f : d * scale * lj;                 // models.py:174-181
+    for (int j0 = wave * 4; j0 < L; j0 += 16) {
+        const float* rows = bqv + (size_t)b * L * D;
+        const float4 d4 = block_dot_row4(bqv + r * D, rows + (size_t)j0 * D, rows + (size_t)min(j0 + 1, L - 1) * D, rows + (size_t)min(j0 + 2, L - 1) * D,
+                                         rows + (size_t)min(j0 + 3, L - 1) * D, D, lane);
+        if (lane < 4 && j0 + lane < L) {
+            const float d = lane == 0 ? d4.x : lane == 1 ? d4.y : lane == 2 ? d4.z : d4.w;
+            const float lj = lmask[(size_t)b * L + j0 + lane];
+            sz[j0 + lane] = lj == 0.f ? -1e9f : d * scale * lj;         // models.py:174-181
         }
     }
     block_softmax(sz, L, t);
@@ -150,9 +172,14 @@ void boundary_self_bwd_rows_kernel(const float* __restrict__ dout, const float* 
     const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const size_t r = (size_t)b * L + i;
     const float lm = lmask[r];
-    for (int j = wave; j < L; j += 4) {
-        const float d = block_dot_row(dout + r * D, fb + ((size_t)b * L + j) * D, D, lane);
-        if (lane == 0) sz[j] = d * lm + dAbm[r * L + j];
+    for (int j0 = wave * 4; j0 < L; j0 += 16) {
+        const float* rows = fb + (size_t)b * L * D;
+        const float4 d4 = block_dot_row4(dout + r * D, rows + (size_t)j0 * D, rows + (size_t)min(j0 + 1, L - 1) * D, rows + (size_t)min(j0 + 2, L - 1) * D,
+                                         rows + (size_t)min(j0 + 3, L - 1) * D, D, lane);
+        if (lane < 4 && j0 + lane < L) {
+            const float d = lane == 0 ? d4.x : lane == 1 ? d4.y : lane == 2 ? d4.z : d4.w;
+            sz[j0 + lane] = d * lm + dAbm[r * L + j0 + lane];
+        }
     }
     __syncthreads();
     if (t < 64) {
@@ -205,9 +232,11 @@ void boundary_self_bwd_cols_kernel(const float* __restrict__ dout, const float* 
     }
     __syncthreads();                                                    // dbaq_lm row visible to the whole block (global, same block)
     __threadfence_block();
-    for (int w = wave; w < Nq; w += 4) {
-        const float d = block_dot_row(dbaq_lm + r * D, fw + ((size_t)b * Nq + w) * D, D, lane);
-        if (lane == 0) sW[w] = d;
+    for (int w0 = wave * 4; w0 < Nq; w0 += 16) {
+        const float* words = fw + (size_t)b * Nq * D;
+        const float4 d4 = block_dot_row4(dbaq_lm + r * D, words + (size_t)w0 * D, words + (size_t)min(w0 + 1, Nq - 1) * D, words + (size_t)min(w0 + 2, Nq - 1) * D,
+                                         words + (size_t)min(w0 + 3, Nq - 1) * D, D, lane);
+        if (lane < 4 && w0 + lane < Nq) sW[w0 + lane] = lane == 0 ? d4.x : lane == 1 ? d4.y : lane == 2 ? d4.z : d4.w;
     }
     __syncthreads();
     if (t < 64) {
