@@ -325,20 +325,21 @@ __device__ __forceinline__ void split_bf16x4(float4 v, uint2 (&out)[NIMG])
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// acc += a * b over the pieces, smallest terms first
-template <int NPROD, int NIMG>
-__device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[NIMG], const bf16x8 (&b)[NIMG], f32x16 c)
+// acc[i][j] += a[i] * b[j] over the pieces, smallest terms first.  Products in the outer loop, the NI x NJ accumulator tiles in the
+// inner one: consecutive MFMAs then write different accumulators (six in a row into one accumulator made every MFMA wait for its
+// predecessor: 52 % matrix-pipe occupancy in the PMC pass).
+template <int NPROD, int NIMG, int NI, int NJ>
+__device__ __forceinline__ void mfma_split_tiles(const bf16x8 (&a)[NI][NIMG], const bf16x8 (&b)[NJ][NIMG], f32x16 (&acc)[NI][NJ])
 {
-    if constexpr (NPROD == 6) {
-        c = mfma_bf16(a[2], b[0], c);
-        c = mfma_bf16(a[0], b[2], c);
-        c = mfma_bf16(a[1], b[1], c);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // piece indices, smallest product first
+#pragma unroll
+    for (int p = 6 - NPROD; p < 6; ++p) {
+        // (NPROD = 3 uses the last three products of the list, NPROD = 1 the last)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_bf16(a[i][PA[p]], b[j][PB[p]], acc[i][j]);
     }
-    if constexpr (NPROD >= 3) {
-        c = mfma_bf16(a[1], b[0], c);
-        c = mfma_bf16(a[0], b[1], c);
-    }
-    return mfma_bf16(a[0], b[0], c);
 }
 constexpr int split_images(int nprod) { return nprod == 6 ? 3 : (nprod == 3 ? 2 : 1); }
 
@@ -349,7 +350,9 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
     // LDS: NIMG bf16 images per operand and buffer, rows of 16 k-values padded to 24 (48 B: the 16-byte fragment reads of
     // 16 consecutive rows fall on 16 different slots).  2 buffers x 2 NIMG x 128 x 48 B = 24,576 / 49,152 / 73,728 B.
     constexpr int NIMG = split_images(NPROD);
-    constexpr int BM = 128, BK = 16, RS = 24, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP, IMG = BM * RS, BUF = 2 * NIMG * IMG;
+    // NPROD = 6: un-padded 32-byte rows with the two 16-byte halves of rows 8..15 (mod 16) swapped -- 49,152 B, three workgroups per CU
+    constexpr bool SWZ = NPROD == 6;
+    constexpr int BM = 128, BK = 16, RS = SWZ ? 16 : 24, KQ = BK / 4, RPP = 256 / KQ, NP = BM / RPP, IMG = BM * RS, BUF = 2 * NIMG * IMG;
     unsigned short* lds = reinterpret_cast<unsigned short*>(smem);
     const int tile_rows = MINI ? 32 : BM;
     const int t = threadIdx.x, lr = t / KQ, kq = (t % KQ) * 4;
@@ -393,7 +396,7 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             uint2 pc[NIMG];
-            const int o = (lr + RPP * p) * RS + kq;
+            const int o = (lr + RPP * p) * RS + (SWZ ? (kq ^ ((((lr + RPP * p) >> 3) & 1) << 3)) : kq);
             split_bf16x4<NIMG>(st.a[p], pc);
 #pragma unroll
             for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(base + i * IMG + o) = pc[i];
@@ -404,8 +407,9 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
     };
     auto compute = [&](int cur) {
         const unsigned short* base = lds + cur * BUF;
-        const unsigned short* ab = base + (wrow + l31) * RS + 8 * h;          // lane (row, h) holds k = 8h .. 8h+7
-        const unsigned short* bb = base + NIMG * IMG + (wcol + l31) * RS + 8 * h;
+        const int hs = SWZ ? 8 * (h ^ ((l31 >> 3) & 1)) : 8 * h;              // (tile rows start at multiples of 32)
+        const unsigned short* ab = base + (wrow + l31) * RS + hs;             // lane (row, h) holds k = 8h .. 8h+7
+        const unsigned short* bb = base + NIMG * IMG + (wcol + l31) * RS + hs;
         bf16x8 af[NMI][NIMG], bf[NMI][NIMG];
 #pragma unroll
         for (int i = 0; i < NMI; ++i)
@@ -414,10 +418,7 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
                 af[i][q] = *reinterpret_cast<const bf16x8*>(ab + q * IMG + i * 32 * RS);
                 bf[i][q] = *reinterpret_cast<const bf16x8*>(bb + q * IMG + i * 32 * RS);
             }
-#pragma unroll
-        for (int i = 0; i < NMI; ++i)
-#pragma unroll
-            for (int j = 0; j < NMI; ++j) acc[i][j] = mfma_split<NPROD, NIMG>(af[i], bf[j], acc[i][j]);
+        mfma_split_tiles<NPROD, NIMG, NMI, NMI>(af, bf, acc);
     };
 
     // One half-step = the matrix products of the resident tile, the split + LDS store of the next one (already in registers) and
@@ -482,10 +483,10 @@ __device__ __forceinline__ void gemm_nt_x3_body(float* smem, const AM& am, const
 }
 
 template <int NPROD, bool KFULL, class AM, class BM_, class EP>
-__global__ __launch_bounds__(256, NPROD == 6 ? 2 : 3)
+__global__ __launch_bounds__(256, 3)
 void gemm_nt_x3_kernel(AM am, BM_ bm, EP ep, int M, int N, int K, int main_tiles_m, int tiles_n, int main_blocks)
 {
-    constexpr int LDS_FLOATS = 2 * 2 * split_images(NPROD) * 128 * 24 / 2;
+    constexpr int LDS_FLOATS = 2 * 2 * split_images(NPROD) * 128 * (NPROD == 6 ? 16 : 24) / 2;
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS < 4 * 32 * GEMM_LDW ? 4 * 32 * GEMM_LDW : LDS_FLOATS];
     if ((int)blockIdx.x < main_blocks) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
@@ -780,10 +781,7 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
                     af[i][q] = lds_read_tr2(pa + roff[sst][0][i][0], pa + roff[sst][0][i][1]);
                     bf[i][q] = lds_read_tr2(pb + roff[sst][1][i][0], pb + roff[sst][1][i][1]);
                 }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NPROD, NIMG>(af[i], bf[j], acc[i][j]);
+            mfma_split_tiles<NPROD, NIMG, 2, 2>(af, bf, acc);
         }
         if (BIAS && tj == 0 && t < BI) {
 #pragma unroll
