@@ -722,7 +722,7 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum = 0.f;
+    float4 bacc = f4zero();                                              // BIAS: this thread's rows of its four columns of A, summed
     const int nk = (max(m_end - m_begin, 0) + BK - 1) / BK;
     struct Stage { float4 a[NPK], b[NPK]; };
     auto g_load = [&](Stage& st, int kt) {
@@ -744,6 +744,7 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
 #pragma unroll
         for (int p = 0; p < NPK; ++p) {
             uint2 pc[NIMG];
+            if (BIAS) bacc = f4add(bacc, st.a[p]);                   // every tile is stored exactly once; rows past the split are zero
             split_bf16x4<NIMG>(st.a[p], pc);
 #pragma unroll
             for (int i = 0; i < NIMG; ++i) *reinterpret_cast<uint2*>(As + i * IMG + buf * TILE + woff[p]) = pc[i];
@@ -783,29 +784,17 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
                 }
             mfma_split_tiles<NPROD, NIMG, 2, 2>(af, bf, acc);
         }
-        if (BIAS && tj == 0 && t < BI) {
-#pragma unroll
-            for (int kk = 0; kk < BK; ++kk) {
-                const unsigned char* e = As + cur * TILE + tn_img_off(kk, t >> 3) + 2 * (t & 7);
-                float v = 0.f;
-#pragma unroll
-                for (int q = NIMG - 1; q >= 0; --q) v += (float)__builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short*>(e + q * IMG));
-                bsum += v;
-            }
-        }
     };
     // as in gemm_nt_x3_body: branch-free half-steps, the split's vector instructions issued between the matrix instructions
     auto half_step = [&](int cur, Stage& st, int kt_next_load) {
         compute(cur);
         s_store(st, cur ^ 1);
         g_load(st, kt_next_load);
-        if (!(BIAS)) {                                               // (the bias variant's column sums are vector work of their own)
-            constexpr int NMFMA = 4 * NPROD * (BK / 16);
+        constexpr int NMFMA = 4 * NPROD * (BK / 16);
 #pragma unroll
-            for (int q = 0; q < NMFMA; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
+        for (int q = 0; q < NMFMA; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
     };
     Stage s0, s1;
@@ -837,7 +826,24 @@ void gemm_tn_bf16_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restr
                 const int j = tj * BJ + wn * 64 + ni * 32 + l31;
                 if (i < I && j < J) out[(size_t)i * J + j] = acc[mi][ni][r];
             }
-    if (BIAS && tj == 0 && t < BI && ti * BI + t < I) bias_slab[(size_t)z * I + ti * BI + t] = bsum;
+    if (BIAS) {
+        // column sums of A over the split's rows (exact fp32 sums of the operand values): the eight row groups of a column quadruple
+        // meet in LDS, in fixed order.  Summed in every tile so that the main loop carries no branch; written by the tj == 0 tiles.
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(tsm);
+        red[lk * 32 + (t & 31)] = bacc;
+        __syncthreads();
+        if (tj == 0 && t < 32) {
+            float4 sum = red[t];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) sum = f4add(sum, red[g * 32 + t]);
+            const int i0 = ti * BI + 4 * t;
+            if (ia == i0) {                                              // (ia is clamped to I - 4 for the last partial quadruple)
+                float* o = bias_slab + (size_t)z * I + i0;
+                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = sum.w;
+            }
+        }
+    }
 }
 
 // number of m-splits so that the grid fills the chip (>= ~2 workgroups per CU)
