@@ -580,7 +580,7 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum = 0.f;
+    float4 bacc = f4zero();                                          // BIAS: this thread's rows of its four columns of A, summed
 
     // Two register stages (see gemm_nt_body): row descriptors and operands of tile kt+3 are requested while tile kt
     // is computed; the virtual-matrix rows change every tile here, so their lookups are part of the prefetch.
@@ -609,6 +609,7 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
     auto s_store = [&](const Stage& st, int buf) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
+            if (BIAS) bacc = f4add(bacc, st.a[p]);                 // every tile is stored exactly once; rows past the split are zero
             stg4(As + buf * BK * BI + (lk + 8 * p) * BI + c4, st.a[p]);
             stg4(Bs + buf * BK * BJ + (lk + 8 * p) * BJ + c4, st.b[p]);
         }
@@ -625,11 +626,6 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
             acc[0][1] = mfma32(a0, b1, acc[0][1]);
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
             acc[1][1] = mfma32(a1, b1, acc[1][1]);
-        }
-        if (BIAS && tj == 0 && t < BI) {
-            const float* col = As + cur * BK * BI + t;
-#pragma unroll
-            for (int kk = 0; kk < BK; ++kk) bsum += col[kk * BI];
         }
     };
 
@@ -666,7 +662,24 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
                 const int j = tj * BJ + wn * 64 + ni * 32 + l31;
                 if (i < I && j < J) out[(size_t)i * J + j] = acc[mi][ni][r];
             }
-    if (BIAS && tj == 0 && t < BI && ti * BI + t < I) bias_slab[(size_t)z * I + ti * BI + t] = bsum;
+    if (BIAS) {
+        // column sums of A over the split's rows: the eight row groups of a column quadruple meet in LDS, in fixed order (summed from
+        // the operand registers in every tile, so the main loop carries no branch; written by the tj == 0 tiles)
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(smem);
+        red[lk * 32 + (t & 31)] = bacc;
+        __syncthreads();
+        if (tj == 0 && t < 32) {
+            float4 sum = red[t];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) sum = f4add(sum, red[g * 32 + t]);
+            const int i0 = ti * BI + 4 * t;
+            if (ia == i0) {                                          // (ia is clamped to I - 4 for a quadruple past the last column)
+                float* o = bias_slab + (size_t)z * I + i0;
+                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = sum.w;
+            }
+        }
+    }
 }
 
 
