@@ -638,16 +638,23 @@ void gemm_tn_kernel(AM am, BM_ bm, float* __restrict__ slab, float* __restrict__
         g_load(s1, 2);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {                                 // tiles kt+1 and kt+2 exist: no conditions inside
         compute(0);
-        if (kt + 1 < nk) s_store(s0, 1);
+        s_store(s0, 1);
         g_load(s0, kt + 3);
         __syncthreads();
+        compute(1);
+        s_store(s1, 0);
+        g_load(s1, kt + 4);
+        __syncthreads();
+    }
+    if (kt < nk) {
+        compute(0);
         if (kt + 1 < nk) {
-            compute(1);
-            if (kt + 2 < nk) s_store(s1, 0);
-            g_load(s1, kt + 4);
+            s_store(s0, 1);
             __syncthreads();
+            compute(1);
         }
     }
 
