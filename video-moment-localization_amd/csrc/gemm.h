@@ -244,18 +244,24 @@ __device__ __forceinline__ void gemm_nt_body(float* smem, const AM& am, const BM
     g_load(s0, 1);
     g_load(s1, 2);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {                                 // tiles kt+1 and kt+2 exist: no conditions inside
         compute(0);                                                // tile kt
-        if (kt + 1 < nk) s_store(s0, 1);                           // tile kt+1
+        s_store(s0, 1);                                            // tile kt+1
         g_load(s0, kt + 3);
         __syncthreads();
-        if (kt + 1 < nk) {
-            compute(1);                                            // tile kt+1
-            if (kt + 2 < nk) s_store(s1, 0);                       // tile kt+2
-            g_load(s1, kt + 4);
-            __syncthreads();
-        }
+        compute(1);                                                // tile kt+1
+        s_store(s1, 0);                                            // tile kt+2
+        g_load(s1, kt + 4);
+        __syncthreads();
     }
+    compute(0);                                                    // tile kt (nk - kt is 1 or 2)
+    if (kt + 1 < nk) {
+        s_store(s0, 1);
+        __syncthreads();
+        compute(1);
+    }
+    __syncthreads();                                               // the accumulator staging below reuses the operand buffers
 
     // Epilogue: C/D layout of a 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each wave
     // writes one 32-row slab of its tile to its private LDS region and reads it back row-major (float4 per lane).
