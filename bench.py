@@ -276,6 +276,51 @@ def main():
             other[mode] = {"ms_per_step": el / args.steps * 1e3, "value": B * world * L * L / (el / args.steps), "unit": "proposals/s",
                            "max_score_deviation_from_f32": dev_max, "arithmetic": notes[mode]}
 
+    def moment_kernels_alone():
+        """The three moment-unit contractions at this step's size, each alone on an otherwise idle device (after a warm-up pass):
+        what the kernels reach without the rest of the step around them (cache state, clocks under sustained mixed load)."""
+        from vml_amd._lib import call, ptr, stream
+        libc = lib.load()
+        lay = models.vml_amd.CellLayout.begin(batch["moment_mask"]).finish()
+        N = lay.N
+        gd = torch.Generator(device=dev).manual_seed(0)
+        r = lambda *sh: torch.randn(*sh, generator=gd, device=dev)
+        fcm, fm_, fb_, x1, dmu = r(N, D), r(N, D), r(B, L, D), r(N, D), r(N, D)
+        W, bvec = r(D, 2 * D) * 0.03, r(D)
+        WT = W.t().contiguous()
+        mu, dfc, dfb = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev), torch.empty(B, L, D, device=dev)
+        dW, db = torch.empty_like(W), torch.empty(D, device=dev)
+        ws = torch.empty(libc.smin_workspace_bytes(N, B, 4, D, 4, 1), dtype=torch.uint8, device=dev)
+        fns = {"moment_fwd": lambda: call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fm_), ptr(fb_), ptr(lay.cells), N, B, L, D, ptr(W), ptr(bvec), ptr(mu), ptr(x1)),
+               "moment_dx": lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb_), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D,
+                                         ptr(WT), ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1)),
+               "moment_dw": lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb_), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D,
+                                         ptr(WT), None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1))}
+        for f in fns.values():                                  # warm-up of all three
+            for _ in range(3):
+                f()
+        out = {}
+        lib.prof_enable(True)
+        for f in fns.values():
+            for _ in range(10):
+                f()
+        torch.cuda.synchronize()
+        lib.prof_enable(False)
+        rec = lib.prof_read()
+        for k in fns:
+            durs = rec.get(k, [])
+            if durs:
+                out[k] = sum(durs) / len(durs)
+        return out
+
+    alone_ms = {}
+    if rank == 0 and world == 1 and args.workload != "longvideo":
+        try:
+            alone_ms = moment_kernels_alone()
+        except Exception as e:                                   # a diagnostic, never fatal
+            alone_ms = {}
+            print(f"# moment_kernels_alone failed: {e}", file=sys.stderr)
+
     def kernel_line(tag, name, flops):
         durs = prof.get(tag, [])
         if not durs:
@@ -286,6 +331,9 @@ def main():
         ach = flops / (avg_ms * 1e-3) / 1e12
         line = {"kernel": name, "achieved": ach, "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": avg_ms, "launches_timed": len(alone) if alone else len(durs),
                 "flops_per_launch": flops}
+        if tag in alone_ms:
+            line["alone_ms"] = alone_ms[tag]
+            line["alone_tflops"] = flops / (alone_ms[tag] * 1e-3) / 1e12
         if alone:
             line["avg_launch_ms_in_timed_region"] = in_step_ms
             line["note"] = "avg_launch_ms: pass without the concurrent weight-gradient stream; in the timed region the two streams share the chip"
