@@ -696,6 +696,37 @@ struct SminCore : torch::autograd::Function<SminCore> {
         CoreState st;
         size_state(st, nl);
 
+        // ---- parameter-only work (weight products, constants, concatenations: ~25 tiny launches) on the second stream from the first
+        // moment of the step, beside the LSTM recurrence that opens the critical path; the main stream waits for it before the proposal map
+        auto mark = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
+        auto await = [](HStream waiter, hipEvent_t e) { TORCH_CHECK(hipStreamWaitEvent(waiter.stream(), e, 0) == hipSuccess, "hipStreamWaitEvent failed"); };
+        std::vector<Tensor> bcat(nl);
+        Tensor bb;
+        hipEvent_t products_ready;
+        wait_stream(prep, curs);                                                    // (the optimizer's update of the parameters)
+        {
+            StreamScope sc(prep);
+            Tensor bsum;
+            std::vector<Tensor> wch;
+            for (int64_t k = 0; k < nl; ++k) {
+                LayerState& ls = st.layer[k];
+                ls.consts = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
+                bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
+                wch.push_back(lp(k, L_CH_W));
+                for (int64_t lo = 0; lo < k; lo += 4) {
+                    std::vector<Tensor> parts;
+                    for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
+                    ls.Pcat[lo / 4] = parts.size() == 1 ? parts[0] : at::cat(parts, 1);
+                }
+                ls.Wcat = at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1);
+                bcat[k] = lp(k, L_FB_B) + lp(k, L_FC_B);
+            }
+            st.Wch_all = nl == 1 ? wch[0] : at::cat(wch);
+            st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
+            bb = at::cat({loc[3], loc[5], loc[7]});
+            products_ready = mark(prep);
+        }
+
         // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
         Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
         Tensor host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
@@ -746,37 +777,20 @@ struct SminCore : torch::autograd::Function<SminCore> {
         Tensor qmf = cont(fl(qm)), lmf = cont(fl(length_mask));
         st.f = f; st.fw = fw; st.fs = fs; st.qmf = qmf; st.lmf = lmf; st.cells = cells; st.row_ptr = row_ptr; st.cellmap = cellmap;
 
-        // ---- parameter-only and word-side work on the second stream
-        std::vector<Tensor> bcat(nl);
+        // ---- word-side operands on the second stream, behind the backbone; the main stream needs them at the first attention only
+        hipEvent_t words_ready;
         wait_stream(prep, curs);
         {
             StreamScope sc(prep);
-            Tensor bsum;
-            std::vector<Tensor> wch;
-            for (int64_t k = 0; k < nl; ++k) {
-                LayerState& ls = st.layer[k];
-                ls.consts = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
-                bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
-                wch.push_back(lp(k, L_CH_W));
-                for (int64_t lo = 0; lo < k; lo += 4) {
-                    std::vector<Tensor> parts;
-                    for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
-                    ls.Pcat[lo / 4] = parts.size() == 1 ? parts[0] : at::cat(parts, 1);
-                }
-                ls.Wcat = at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1);
-                bcat[k] = lp(k, L_FB_B) + lp(k, L_FC_B);
-            }
-            st.Wch_all = nl == 1 ? wch[0] : at::cat(wch);
-            st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
             std::vector<const float*> pp;
             for (int64_t k = 0; k < nl; ++k)
                 for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) pp.push_back(fp(lp(k, which)));
             st.what = at::empty({nl, B, Nq, dl}, opt); st.kb = at::empty({nl, B, Nq, dl}, opt); st.Mq = at::empty({nl, B, Nq, dl}, opt);
             st.shat = at::empty({nl, B, dl}, opt); st.uq = at::empty({nl, B, Nq}, opt);
             SMIN_CK(smin_word_prep_fwd(cur(), fp(fw), fp(fs), fp(qmf), pp.data(), i32(nl), B, Nq, D, dl, fpm(st.what), fpm(st.shat), fpm(st.kb), fpm(st.Mq), fpm(st.uq)));
+            words_ready = mark(prep);
         }
-        Tensor bb = at::cat({loc[3], loc[5], loc[7]});
-        wait_stream(curs, prep);
+        if (prep != curs) await(curs, products_ready);
         // Tensors cross streams here without recordStream bookkeeping (an event record and queries per tensor and step: ~0.3 ms of
         // host time).  What makes that safe: (1) every stretch of work on another stream starts with a wait for the main stream and
         // the main stream waits for every other stream before forward / backward return; (2) no tensor that another stream has
@@ -833,6 +847,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 chat = y;
             }
             ls.chat = chat;
+            if (k == 0 && prep != curs) await(curs, words_ready);
             ls.cc = at::empty({lastl ? 0 : N * C, dl}, opt); ls.ccmean = at::empty({N, dl}, opt);
             SMIN_CK(smin_content_attn_fwd(cur(), fp(chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]), fp(st.shat[k]), fp(qmf),
                                           lastl ? nullptr : fpm(ls.cc), fpm(ls.ccmean)));
