@@ -24,3 +24,9 @@ for i, (s, e, name, q) in enumerate(w):
         prev = w[i - 1][2][:70] if i else "-"
         print(f"  +{(s - a) / 1e3:9.1f} us  gap {(s - busy_until) / 1e3:7.1f} us   after [{prev}]  before [q{q}] {name[:70]}")
     busy_until = max(busy_until, e)
+if len(sys.argv) > 3:                                   # third argument: list every kernel of the first <n> microseconds of the step
+    lim = float(sys.argv[3]) * 1000
+    for s, e, name, q in w:
+        if s - a > lim:
+            break
+        print(f"    +{(s - a) / 1e3:8.1f} .. {(e - a) / 1e3:8.1f} us  q{q}  {name[:90]}")

@@ -767,12 +767,16 @@ struct SminCore : torch::autograd::Function<SminCore> {
         const int64_t N = host_n.const_data_ptr<int64_t>()[0];
         const int n = i32(N);
         Tensor cells, row_ptr, cellmap;
+        Tensor mask8 = mm.contiguous().view(at::kByte);
+        hipEvent_t layout_ready;
+        if (prep != curs) await(prep, count_ready);                               // (the mask; the second stream is idle while the LSTM runs)
         {
+            StreamScope sc(prep);
             auto io = at::TensorOptions().dtype(at::kInt).device(dev);
-            Tensor mask8 = mm.contiguous().view(at::kByte);
             cells = at::empty({N, 4}, io); row_ptr = at::empty({Bq * L + 1}, io); cellmap = at::empty({Bq, L, L}, io);
             SMIN_CK(smin_build_cells(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), B, Li, 0, cells.data_ptr<int32_t>(), row_ptr.data_ptr<int32_t>(),
                                      cellmap.data_ptr<int32_t>()));
+            layout_ready = mark(prep);
         }
         Tensor qmf = cont(fl(qm)), lmf = cont(fl(length_mask));
         st.f = f; st.fw = fw; st.fs = fs; st.qmf = qmf; st.lmf = lmf; st.cells = cells; st.row_ptr = row_ptr; st.cellmap = cellmap;
@@ -790,7 +794,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             SMIN_CK(smin_word_prep_fwd(cur(), fp(fw), fp(fs), fp(qmf), pp.data(), i32(nl), B, Nq, D, dl, fpm(st.what), fpm(st.shat), fpm(st.kb), fpm(st.Mq), fpm(st.uq)));
             words_ready = mark(prep);
         }
-        if (prep != curs) await(curs, products_ready);
+        if (prep != curs) { await(curs, products_ready); await(curs, layout_ready); }
         // Tensors cross streams here without recordStream bookkeeping (an event record and queries per tensor and step: ~0.3 ms of
         // host time).  What makes that safe: (1) every stretch of work on another stream starts with a wait for the main stream and
         // the main stream waits for every other stream before forward / backward return; (2) no tensor that another stream has
