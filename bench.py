@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra timings of the bf16-core contraction modes")
-    ap.add_argument("--gemm", "--dtype", dest="gemm", default="f32", choices=["f32", "f32e", "bf16x3", "bf16"],
+    ap.add_argument("--gemm", "--dtype", dest="gemm", default=os.environ.get("SMIN_GEMM_MODE", "f32"), choices=["f32", "f32e", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (f32 = the reference's, the headline; bf16 = BASELINE.json configs[1])")
     ap.add_argument("--feed", default="resident", choices=["resident", "host"],
                     help="resident (default, the headline): inputs live in HBM; host: every step's batch comes through BatchFeeder "

@@ -314,6 +314,8 @@ int smin_sum_lists(void* stream, const float* const* srcs, int n, size_t numel, 
 /* ---- stand-alone fp32 MFMA GEMM  C[M][N] = A[M][K] * B[N][K]^T  (used by tests and bench.py's
  * roofline probe; same engine as every contraction above). */
 int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K);
+/* C += A * B^T through the engine's accumulate epilogue (tests) */
+int smin_gemm_nt_acc(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
+    "smin_gemm_nt_acc": [_vp] * 4 + [_i] * 3,
     "smin_clip_window_means_fwd": [_vp] * 3 + [_i, _vp] + [_i] * 7 + [_vp, _vp, _sz],
     "smin_clip_window_means_bwd": [_vp] * 5 + [_i] * 7 + [_vp, _vp, _sz, _vp, _vp],
     "smin_content_attn_fwd": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
@@ -106,6 +107,8 @@ def load():
     if lib.smin_abi_version() != 1:
         raise SminHipError("libsmin_hip.so ABI version mismatch")
     _lib = lib
+    if DEFAULT_GEMM_MODE != "f32":                        # deployment switch: SMIN_GEMM_MODE=f32e|bf16x3|bf16 (see set_gemm_mode)
+        check(lib.smin_set_gemm_mode(GEMM_MODES[DEFAULT_GEMM_MODE]), "smin_set_gemm_mode")
     return lib
 
 
@@ -189,6 +192,9 @@ def prof_read(cap=1 << 16):
 
 
 GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "f32e": 3}
+DEFAULT_GEMM_MODE = os.environ.get("SMIN_GEMM_MODE", "f32")      # the mode the library starts in (and tests restore)
+if DEFAULT_GEMM_MODE not in GEMM_MODES:
+    raise ValueError(f"SMIN_GEMM_MODE={DEFAULT_GEMM_MODE!r}: expected one of {sorted(GEMM_MODES)}")
 
 
 def set_gemm_mode(mode):

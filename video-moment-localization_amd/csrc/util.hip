@@ -277,6 +277,24 @@ extern "C" int smin_sum_lists(void* stream, const float* const* srcs, int n, siz
     return 0;
 }
 
+namespace smin {
+struct EpAccumTest {                // out += acc (same visit as the boundary unit's accumulate epilogue)
+    float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            float* o = out + (size_t)row * N + col;
+            stg4(o, f4add(v, ldg4(o)));
+        });
+    }
+};
+}  // namespace smin
+/* C[M][N] += A[M][K] * B[N][K]^T  (test entry: the accumulate epilogue of the engine) */
+extern "C" int smin_gemm_nt_acc(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K)
+{
+    SMIN_REQUIRE(K % 4 == 0 && N % 4 == 0);
+    return launch_gemm_nt((hipStream_t)stream, PlainMat{A, K}, PlainMat{Bm, K}, EpAccumTest{Cm}, M, N, K);
+}
+
 extern "C" int smin_gemm_nt(void* stream, const float* A, const float* Bm, float* Cm, int M, int N, int K)
 {
     SMIN_REQUIRE(K % 4 == 0 && N % 4 == 0);
