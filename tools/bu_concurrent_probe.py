@@ -2,7 +2,9 @@
 from repetition to repetition?  MODE=f32e L=64 BG=nt|tn|ntk16|mm|copy [ZERO_WQ=1]
 Finding (round 2): with a bf16-core contraction kernel of this library as the neighbour (BG=nt / tn, MODE != f32) a handful of dfb
 entries lose one addend (a 16-byte global load of the accumulation loop comes back as zeros); inputs stay intact, every
-intermediate in the workspace is identical; never with MODE=f32, rocBLAS (mm), copies or a one-tile K loop (ntk16) as neighbour."""
+intermediate in the workspace is identical; never with MODE=f32, rocBLAS (mm), copies or a one-tile K loop (ntk16) as neighbour.
+Cause: packed fp32 arithmetic (v_pk_fma_f32 ...) in the victim beside v_mfma_f32_32x32x16_bf16 of the neighbour; the library is
+now built without packed fp32 arithmetic (csrc/Makefile NOPACK) and this probe reports 0 differing entries."""
 import os, sys, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
