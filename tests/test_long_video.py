@@ -134,3 +134,43 @@ def test_compute_ious_long_video(dev):
         a = [torch.rand(2, L2, L2, generator=g) * mm2, torch.rand(2, L2, generator=g), torch.rand(2, L2, generator=g), mm2,
              torch.rand(2, L2, L2, generator=g) * mm2]
         assert models.vml_amd.compute_ious(*(x.to(dev) for x in a)) == models.vml_amd.compute_ious_torch(*a)
+
+
+@pytest.mark.gpu
+def test_bf16_core_modes_reproducible_under_all_streams(dev):
+    """Regression for the packed-fp32 / bf16-MFMA interaction of DESIGN 3.4: with the contractions on the bf16 matrix cores and every
+    stream of the step in use (boundary stream, weight stream, and -- by the test switch -- the torch-side parameter work on the
+    second stream too), repeated forward + backward passes on the same weights and batch give bit-identical scores and gradients.
+    Before the library was built without packed fp32 arithmetic this failed within a few repetitions at this shape."""
+    import os
+    import models
+    from vml_amd import loss_fn
+    from oracle import smin_oracle as O
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 1024, 512, 4, 512, 128, 3, 500, 20, 256, 2
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.1)
+    m = models.SMIN(T, L, C, D, dl, layers, Din, Nq, Hh, dev)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    batch = O.synthetic_batch(B, T, L, Nq, Din, seed=3)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    old_env = os.environ.get("SMIN_STREAMS_IN_ALL_MODES")
+    os.environ["SMIN_STREAMS_IN_ALL_MODES"] = "1"
+    models.vml_amd.set_gemm_mode("f32e")
+    try:
+        def run():
+            m.zero_grad(set_to_none=True)
+            out = m(*H.model_inputs(b))
+            loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+            torch.cuda.synchronize()
+            return [out[0].detach().clone()] + [p.grad.clone() for p in m.parameters()]
+        ref = run()
+        for rep in range(5):
+            cur = run()
+            for i, (x, y) in enumerate(zip(ref, cur)):
+                assert torch.equal(x, y), (rep, i)
+    finally:
+        models.vml_amd.set_gemm_mode(models.vml_amd._lib.DEFAULT_GEMM_MODE)
+        if old_env is None:
+            os.environ.pop("SMIN_STREAMS_IN_ALL_MODES", None)
+        else:
+            os.environ["SMIN_STREAMS_IN_ALL_MODES"] = old_env
