@@ -303,6 +303,20 @@ int smin_build_cells(void* stream, const uint8_t* mask, int B, int L, int all_ce
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);
 int smin_unpack_cells(void* stream, const float* packed, const int32_t* cells, int N, int L, int W, float* dense /* pre-zeroed */);
 
+/* ---- parameter-only operands of the content stream and the moment unit, every layer in one launch per direction
+ * (csrc/param_prep.hip).  params: HOST array of nl*8 device pointers, per layer [Wch (dl,D) = linear_c_hat.weight, bch, Wc (D,dl) =
+ * linear_c.weight, bc, Wfb (D,D) = conv_layer_fb.weight, bfb, Wfc (D,D) = conv_layer_fc.weight, bfc]  (models.py:247, 269, 288-303).
+ *   Pcat: HOST array of nl*2 device pointers; entry [k*2 + part] (k > 4*part) is [dl][nseg*dl], nseg = min(4, k - 4 part), column block
+ *         s = Wch_k Wc_{4 part + s};   consts [nl][dl] = bch_k + Wch_k (bc_0 + .. + bc_{k-1});   Wcat [nl][D][2D] = [Wfb_k | Wfc_k];
+ *         bcat [nl][D] = bfb_k + bfc_k;   Wch_all [nl*dl][D].       nl <= 8, D % 32 == 0, D <= 1056, dl % 32 == 0.
+ * Backward: dPcat (as Pcat), dconsts, dWcat, dbcat, dWch_all; *_base: HOST arrays of nl device pointers with the gradient a parameter
+ * already has from its direct uses (dWch_base[k] may be NULL); grads: HOST array of nl*8 device pointers, every entry written. */
+int smin_param_prep_fwd(void* stream, const float* const* params, int nl, int D, int dl, float* const* Pcat, float* consts, float* Wcat,
+                        float* bcat, float* Wch_all);
+int smin_param_prep_bwd(void* stream, const float* const* params, int nl, int D, int dl, const float* const* dPcat, const float* dconsts,
+                        const float* dWcat, const float* dbcat, const float* dWch_all, const float* const* dWch_base,
+                        const float* const* dWc_base, const float* const* dbc_base, float* const* grads);
+
 /* ---- host helpers of the fused step: many small tensors in one launch.  src/dst/rows/cols/srcs are HOST arrays.
  *   smin_transpose_batch: dst[m] [cols][rows] = src[m]^T for n <= SMIN_BATCH_MAX row-major matrices src[m] [rows][cols]
  *     (the W^T operands of the input-gradient contractions; the reference transposes inside autograd, models.py every nn.Linear);

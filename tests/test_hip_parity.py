@@ -900,6 +900,70 @@ def test_step_helpers_through_the_c_abi(dev):
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
 
 
+@pytest.mark.parametrize("nl,D,dl", [(3, 512, 128), (1, 64, 32), (6, 96, 32), (8, 64, 64)])
+def test_param_prep_kernels(dev, nl, D, dl):
+    """csrc/param_prep.hip (every layer's parameter-only operands of the content stream and the moment unit in one launch per
+    direction) against the torch formulas it replaces and their autograd gradients, in fp64."""
+    import ctypes
+    import models
+    from vml_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(nl * 1000 + D + dl)
+    r = lambda *s: torch.randn(*s, generator=g)
+    P = [[r(dl, D) * 0.1, r(dl), r(D, dl) * 0.1, r(D), r(D, D) * 0.1, r(D), r(D, D) * 0.1, r(D)] for _ in range(nl)]
+    Pd = [[t.to(dev) for t in row] for row in P]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+    nseg = lambda k, part: min(4, k - 4 * part)
+    Pcat = [[(torch.empty(dl, nseg(k, part) * dl, device=dev) if k > 4 * part else None) for part in range(2)] for k in range(nl)]
+    consts, Wcat, bcat, Wch_all = torch.empty(nl, dl, device=dev), torch.empty(nl, D, 2 * D, device=dev), torch.empty(nl, D, device=dev), torch.empty(nl * dl, D, device=dev)
+    call("smin_param_prep_fwd", stream(), arr([t for row in Pd for t in row]), nl, D, dl, arr([t for row in Pcat for t in row]), ptr(consts), ptr(Wcat), ptr(bcat),
+         ptr(Wch_all))
+    # reference (fp64, autograd)
+    R = [[t.double().requires_grad_(True) for t in row] for row in P]
+    ref_P, ref_c = [], []
+    bsum = None
+    for k in range(nl):
+        ref_c.append(R[k][1] + (R[k][0] @ bsum if bsum is not None else 0))
+        bsum = R[k][3] if bsum is None else bsum + R[k][3]
+        ref_P.append([torch.cat([R[k][0] @ R[l][2] for l in range(4 * part, min(4 * part + 4, k))], 1) if k > 4 * part else None for part in range(2)])
+    ref_Wcat = torch.stack([torch.cat([R[k][4], R[k][6]], 1) for k in range(nl)])
+    ref_bcat = torch.stack([R[k][5] + R[k][7] for k in range(nl)])
+    ref_all = torch.cat([R[k][0] for k in range(nl)])
+    tol = lambda ref: 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    for k in range(nl):
+        assert (consts[k].cpu().double() - ref_c[k].detach()).abs().max().item() < tol(ref_c[k])
+        for part in range(2):
+            if Pcat[k][part] is not None:
+                assert (Pcat[k][part].cpu().double() - ref_P[k][part].detach()).abs().max().item() < tol(ref_P[k][part]), (k, part)
+    assert torch.equal(Wcat.cpu().double(), ref_Wcat.detach()) and torch.equal(Wch_all.cpu().double(), ref_all.detach())
+    assert (bcat.cpu().double() - ref_bcat.detach()).abs().max().item() < 1e-6
+    # backward
+    dP = [[(r(*Pcat[k][part].shape) if Pcat[k][part] is not None else None) for part in range(2)] for k in range(nl)]
+    dconsts, dWcat, dbcat, dall = r(nl, dl), r(nl, D, 2 * D), r(nl, D), r(nl * dl, D)
+    base_ch = [(r(dl, D) if k > 0 else None) for k in range(nl)]
+    base_c, base_bc = [r(D, dl) for _ in range(nl)], [r(D) for _ in range(nl)]
+    loss = (ref_Wcat * dWcat.double()).sum() + (ref_bcat * dbcat.double()).sum() + (ref_all * dall.double()).sum()
+    for k in range(nl):
+        loss = loss + (ref_c[k] * dconsts[k].double()).sum() + (R[k][2] * base_c[k].double()).sum() + (R[k][3] * base_bc[k].double()).sum()
+        if base_ch[k] is not None:
+            loss = loss + (R[k][0] * base_ch[k].double()).sum()
+        for part in range(2):
+            if dP[k][part] is not None:
+                loss = loss + (ref_P[k][part] * dP[k][part].double()).sum()
+    loss.backward()
+    grads = [[torch.full_like(t, 7.0) for t in row] for row in Pd]
+    dv = lambda t: None if t is None else t.to(dev)
+    dPd = [[dv(t) for t in row] for row in dP]
+    bch_d, bc_d, bbc_d = [dv(t) for t in base_ch], [dv(t) for t in base_c], [dv(t) for t in base_bc]
+    dcd, dWd, dbd, dad = dconsts.to(dev), dWcat.to(dev), dbcat.to(dev), dall.to(dev)
+    call("smin_param_prep_bwd", stream(), arr([t for row in Pd for t in row]), nl, D, dl, arr([t for row in dPd for t in row]), ptr(dcd), ptr(dWd), ptr(dbd), ptr(dad),
+         arr(bch_d), arr(bc_d), arr(bbc_d), arr([t for row in grads for t in row]))
+    for k in range(nl):
+        for q in range(8):
+            ref = R[k][q].grad
+            err = (grads[k][q].cpu().double() - ref).abs().max().item()
+            assert err < 5e-5 * max(1.0, float(ref.abs().max())), (k, q, err)
+
+
 def test_degenerate_samples_and_empty_batch(dev):
     """A sample with a single valid snippet, a sample with none, inference under no_grad, and a batch without any valid
     cell (N = 0) with its backward -- the edge cases of the packed layout."""

@@ -23,6 +23,8 @@ SIGNATURES = {
     "smin_prof_read": [_vp, _vp, _i],
     "smin_workspace_bytes": [_i] * 6,
     "smin_transpose_batch": [_vp] * 5 + [_i],
+    "smin_param_prep_fwd": [_vp, _vp, _i, _i, _i] + [_vp] * 5,
+    "smin_param_prep_bwd": [_vp, _vp, _i, _i, _i] + [_vp] * 9,
     "smin_sum_lists": [_vp, _vp, _i, _sz, _vp],
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
     "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp, _vp],
