@@ -247,8 +247,9 @@ def test_batch_targets_on_device(dev):
 def test_native_host_equals_python_host(dev):
     """The torch-extension host (csrc/torch_binding.cpp) with a node per module and the Python host (functional.py / modules.py)
     drive the same kernels in the same order: scores and every parameter gradient must agree bit for bit.  The default host runs
-    proposal map + SMI layers + localization as ONE node (SminCore): same forward launches (scores bit-equal), gradients of tensors
-    with several consumers are summed in one launch instead of by the autograd engine (a different but fixed order: tight tolerance)."""
+    whole model as ONE node (SminCore): the same kernels except for the parameter products (its own kernel instead of hipBLASLt: scores
+    within 2e-6); gradients of tensors with several consumers are summed in one launch instead of by the autograd engine (a different
+    but fixed order: tight tolerance)."""
     from oracle import smin_oracle as O
     import vml_amd.training as TR
     from vml_amd import loss_fn
@@ -272,9 +273,10 @@ def test_native_host_equals_python_host(dev):
                 TR.NATIVE_LOSS = True
             res.append(([o.detach().clone() for o in out], loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
         (o0, l0, g0), (o1, l1, g1), (o2, l2, g2) = res
-        assert torch.equal(l1, l2) and torch.equal(l0, l1)
+        assert torch.equal(l1, l2) and abs(float(l0) - float(l1)) <= 2e-6 * max(1.0, abs(float(l1)))
         for x, y, z in zip(o0, o1, o2):
-            assert torch.equal(y, z) and torch.equal(x, y)
+            assert torch.equal(y, z)
+            assert float((x - y).abs().max()) <= 2e-6          # (the one-node step forms the weight products with its own kernel: last-bit differences)
         gmax = max(float(v.abs().max()) for v in g1.values())
         for k in g1:
             assert torch.equal(g1[k], g2[k]), k

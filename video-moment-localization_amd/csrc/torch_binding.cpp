@@ -703,29 +703,47 @@ struct SminCore : torch::autograd::Function<SminCore> {
         std::vector<Tensor> bcat(nl);
         Tensor bb;
         hipEvent_t products_ready;
+        const bool prep_kernel = D % 32 == 0 && D <= 1056 && dl % 32 == 0 && nl <= 8;   // limits of csrc/param_prep.hip (else: torch calls)
         wait_stream(prep, curs);                                                    // (the optimizer's update of the parameters)
         {
             StreamScope sc(prep);
-            Tensor bsum;
-            std::vector<Tensor> wch;
-            for (int64_t k = 0; k < nl; ++k) {
-                LayerState& ls = st.layer[k];
-                ls.consts = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
-                bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
-                wch.push_back(lp(k, L_CH_W));
-                for (int64_t lo = 0; lo < k; lo += 4) {
-                    std::vector<Tensor> parts;
-                    for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
-                    ls.Pcat[lo / 4] = parts.size() == 1 ? parts[0] : at::cat(parts, 1);
+            if (prep_kernel) {
+                Tensor consts_all = at::empty({nl, dl}, opt), Wcat_all = at::empty({nl, D, 2 * D}, opt), bcat_all = at::empty({nl, D}, opt);
+                st.Wch_all = at::empty({nl * dl, D}, opt);
+                std::vector<const float*> pp;
+                std::vector<float*> pc(nl * 2, nullptr);
+                for (int64_t k = 0; k < nl; ++k) {
+                    for (int which : {L_CH_W, L_CH_B, L_C_W, L_C_B, L_FB_W, L_FB_B, L_FC_W, L_FC_B}) pp.push_back(fp(lp(k, which)));
+                    LayerState& ls = st.layer[k];
+                    for (int64_t lo = 0; lo < k; lo += 4) {
+                        ls.Pcat[lo / 4] = at::empty({dl, std::min<int64_t>(4, k - lo) * dl}, opt);
+                        pc[k * 2 + lo / 4] = fpm(ls.Pcat[lo / 4]);
+                    }
+                    ls.consts = consts_all[k]; ls.Wcat = Wcat_all[k]; bcat[k] = bcat_all[k];
                 }
-                ls.Wcat = at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1);
-                bcat[k] = lp(k, L_FB_B) + lp(k, L_FC_B);
+                SMIN_CK(smin_param_prep_fwd(cur(), pp.data(), i32(nl), D, dl, pc.data(), fpm(consts_all), fpm(Wcat_all), fpm(bcat_all), fpm(st.Wch_all)));
+            } else {
+                Tensor bsum;
+                std::vector<Tensor> wch;
+                for (int64_t k = 0; k < nl; ++k) {
+                    LayerState& ls = st.layer[k];
+                    ls.consts = bsum.defined() ? lp(k, L_CH_B) + at::mv(lp(k, L_CH_W), bsum) : lp(k, L_CH_B);
+                    bsum = bsum.defined() ? bsum + lp(k, L_C_B) : lp(k, L_C_B);
+                    wch.push_back(lp(k, L_CH_W));
+                    for (int64_t lo = 0; lo < k; lo += 4) {
+                        std::vector<Tensor> parts;
+                        for (int64_t l = lo; l < std::min(lo + 4, k); ++l) parts.push_back(at::matmul(lp(k, L_CH_W), lp(l, L_C_W)));
+                        ls.Pcat[lo / 4] = parts.size() == 1 ? parts[0] : at::cat(parts, 1);
+                    }
+                    ls.Wcat = at::cat({lp(k, L_FB_W).view({D, D}), lp(k, L_FC_W).view({D, D})}, 1);
+                    bcat[k] = lp(k, L_FB_B) + lp(k, L_FC_B);
+                }
+                st.Wch_all = nl == 1 ? wch[0] : at::cat(wch);
             }
-            st.Wch_all = nl == 1 ? wch[0] : at::cat(wch);
-            st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
-            bb = at::cat({loc[3], loc[5], loc[7]});
             products_ready = mark(prep);
         }
+        st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});      // (two tiny torch launches, main stream)
+        bb = at::cat({loc[3], loc[5], loc[7]});
 
         // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
         Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
@@ -877,7 +895,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
         visit_state(st, [&](Tensor& t) { flat.push_back(t); });
         for (auto& p : all) flat.push_back(p);
         ctx->save_for_backward(flat);
-        ctx->saved_data["d"] = std::vector<int64_t>{N, T, L, C, nl, flags, H, Nq_in};
+        ctx->saved_data["d"] = std::vector<int64_t>{N, T, L, C, nl, flags, H, Nq_in, prep_kernel ? 1 : 0};
         return {pm, psea};
     }
 
@@ -885,6 +903,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
     {
         auto d = ctx->saved_data["d"].toIntVector();
         const int64_t N = d[0], T = d[1], L = d[2], C = d[3], nl = d[4], flags = d[5], H = d[6], Nq_in = d[7];
+        const bool prep_kernel = d[8] != 0;
         auto sv = ctx->get_saved_variables();
         CoreState st;
         size_state(st, nl);
@@ -939,6 +958,13 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
 
         std::vector<Tensor> dcc(nl), dHs(nl), dchat(nl), dconsts(nl), dfs_parts, dfw_parts;
+        // prep_kernel: the gradients that meet in the parameter products are gathered as the kernel of csrc/param_prep.hip wants them
+        Tensor dconsts_all, dWcat_all, dbcat_all, dWch_all;
+        std::vector<Tensor> base_ch(nl), base_c(nl), base_bc(nl);
+        if (prep_kernel) {
+            dconsts_all = at::empty({nl, dl}, opt); dWcat_all = at::empty({nl, D, 2 * D}, opt); dbcat_all = at::empty({nl, D}, opt);
+            for (int64_t k = 0; k < nl; ++k) dconsts[k] = dconsts_all[k];
+        }
         std::vector<std::vector<Tensor>> dPcat(nl);
         Tensor dwhat = at::empty_like(st.what), dshat = at::empty_like(st.shat), dMq = at::empty_like(st.Mq), duq = at::empty_like(st.uq);
         if (N == 0) { dwhat.zero_(); dshat.zero_(); dMq.zero_(); duq.zero_(); }
@@ -952,12 +978,14 @@ struct SminCore : torch::autograd::Function<SminCore> {
             wait_stream(wstr, curs);
             {
                 StreamScope sc(wstr);
-                Tensor dWcat = at::empty_like(ls.Wcat), dbcat = at::empty({D}, opt);
+                Tensor dWcat = prep_kernel ? dWcat_all[k] : at::empty_like(ls.Wcat), dbcat = prep_kernel ? dbcat_all[k] : at::empty({D}, opt);
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
                                              fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(ls.x1)));
-                dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
-                dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
+                if (!prep_kernel) {
+                    dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
+                    dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
+                }
             }
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
@@ -1027,14 +1055,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
                     const float* xs[1] = {fp(ls.ccmean)};
                     auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(n, D, dl), dev);
                     SMIN_CK(smin_linear_rows_bwd(cur(), fp(dcum), xs, 1, nullptr, n, D, dl, nullptr, fpm(dWc), fpm(dbc), ws.p, ws.n));
-                    acc(dlp(k, L_C_W), dWc); acc(dlp(k, L_C_B), dbc);
+                    if (prep_kernel) { base_c[k] = dWc; base_bc[k] = dbc; }
+                    else { acc(dlp(k, L_C_W), dWc); acc(dlp(k, L_C_B), dbc); }
                 }
                 for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
                     const int nseg = i32(std::min<int64_t>(4, k - lo));
                     const float* xs[4];
                     for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
                     Tensor dP = at::empty_like(ls.Pcat[part]);
-                    if (lo == 0) dconsts[k] = at::empty({dl}, opt);
+                    if (lo == 0 && !prep_kernel) dconsts[k] = at::empty({dl}, opt);
                     auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(i32(N * C), dl, nseg * dl), dev);
                     SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, nullptr, i32(N * C), dl, dl, nullptr, fpm(dP), lo == 0 ? fpm(dconsts[k]) : nullptr, ws.p, ws.n));
                     dPcat[k].push_back(dP);
@@ -1044,7 +1073,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                     const float* xs[1] = {fp(ls.Hs)};
                     auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(n, dl, D), dev);
                     SMIN_CK(smin_linear_rows_bwd(cur(), fp(dhp), xs, 1, nullptr, n, dl, D, nullptr, fpm(dWch), nullptr, ws.p, ws.n));
-                    acc(dlp(k, L_CH_W), dWch);
+                    if (prep_kernel) base_ch[k] = dWch; else acc(dlp(k, L_CH_W), dWch);
                 }
             }
             // gate: every consumer of hbar_k (clip-mean update, boundary unit, the later layers' running sums) and of f_m (residual; layer 0: the clip-mean chain)
@@ -1104,7 +1133,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
             SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
                                                tab.second.data_ptr()));
-            dconsts[0] = dchat[0].sum(0);
+            if (prep_kernel) at::sum_out(dconsts[0], dchat[0], at::IntArrayRef{0}); else dconsts[0] = dchat[0].sum(0);
             Tensor df1 = at::empty({B, T, D}, opt);
             keep.push_back(dg);
             const float* xs[1] = {fp(f)}; float* dxs[1] = {fpm(df1)};
@@ -1113,10 +1142,10 @@ struct SminCore : torch::autograd::Function<SminCore> {
             wait_stream(wstr, curs);
             {
                 StreamScope sc(wstr);
-                Tensor dWch_all = at::empty_like(st.Wch_all);
+                dWch_all = at::empty_like(st.Wch_all);
                 auto wsw = scratch(smin_linear_rows_bwd_workspace_bytes(i32(B * T), i32(nl * dl), D), dev);
                 SMIN_CK(smin_linear_rows_bwd(cur(), fp(dg), xs, 1, nullptr, i32(B * T), i32(nl * dl), D, nullptr, fpm(dWch_all), nullptr, wsw.p, wsw.n));
-                for (int64_t k = 0; k < nl; ++k) acc(dlp(k, L_CH_W), dWch_all.slice(0, k * dl, (k + 1) * dl));
+                if (!prep_kernel) for (int64_t k = 0; k < nl; ++k) acc(dlp(k, L_CH_W), dWch_all.slice(0, k * dl, (k + 1) * dl));
             }
             weights_done = mark(wstr);
             df = at::empty({B, T, D}, opt);
@@ -1128,7 +1157,22 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
         // ---- parameter products on the second stream: consts_k = b_ch_k + Wch_k bsum_k (bsum_k = sum_{l<k} b_c_l), Pcat_k = [Wch_k Wc_l]_l
         if (tail != wstr) await(tail, weights_done);
-        {
+        if (prep_kernel) {
+            StreamScope sc(tail);
+            std::vector<const float*> pp, dpc(nl * 2, nullptr), bch(nl, nullptr), bc(nl), bbc(nl);
+            std::vector<float*> gp;
+            for (int64_t k = 0; k < nl; ++k) {
+                for (int which : {L_CH_W, L_CH_B, L_C_W, L_C_B, L_FB_W, L_FB_B, L_FC_W, L_FC_B}) {
+                    pp.push_back(fp(lp(k, which)));
+                    dlp(k, which) = at::empty_like(lp(k, which));
+                    gp.push_back(fpm(dlp(k, which)));
+                }
+                for (size_t part = 0; part < dPcat[k].size(); ++part) dpc[k * 2 + part] = fp(dPcat[k][part]);
+                bch[k] = fp(base_ch[k]); bc[k] = fp(base_c[k]); bbc[k] = fp(base_bc[k]);
+            }
+            SMIN_CK(smin_param_prep_bwd(cur(), pp.data(), i32(nl), D, dl, dpc.data(), fp(dconsts_all), fp(dWcat_all), fp(dbcat_all), fp(dWch_all), bch.data(), bc.data(),
+                                        bbc.data(), gp.data()));
+        } else {
             StreamScope sc(tail);
             Tensor bsum;
             std::vector<Tensor> bsums(nl);

@@ -543,6 +543,11 @@ class SMIN(nn.Module):
         from . import _lib
         return kind == "library" or _lib.get_gemm_mode() == "f32" or bool(os.environ.get("SMIN_STREAMS_IN_ALL_MODES"))
 
+    def _prep_is_library_code(self):
+        """The one-node step forms the parameter products with csrc/param_prep.hip when its shape limits hold (torch_binding.cpp):
+        then nothing of torch runs on the second stream and the overlap is safe in every contraction mode."""
+        return self.fused_core and self.D % 32 == 0 and self.D <= 1056 and self.dl % 32 == 0 and len(self.smis) <= 8
+
     def _native_ok(self, video_features, query_features):
         """The torch-extension path covers the production configuration: content stream on a mask-driven cell list, fused
         BiLSTM and video encoder kernels.  Anything else (dl >= D, C outside 2..4, > 8 layers, H > 256, odd widths) runs the
@@ -558,7 +563,8 @@ class SMIN(nn.Module):
         if self._native_ok(video_features, query_features):
             from . import _lib
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
-                   int(self.overlap_boundary), int(self.overlap_prep and self._streams_allowed("torch")), int(self.fused_core), int(self.async_weights)]
+                   int(self.overlap_boundary), int(self.overlap_prep and (self._streams_allowed("torch") or self._prep_is_library_code())), int(self.fused_core),
+                   int(self.async_weights)]
             return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
                                                   self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
