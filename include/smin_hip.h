@@ -251,6 +251,8 @@ int smin_linear_rows_fwd(void* stream, const float* const* xs, int nseg, const f
 size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot);
 int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, int nseg, const float* WT, int R, int O, int K,
                          float* const* dxs, float* dW, float* dbias, void* ws, size_t ws_bytes);
+/* dx_s += dy W_s for every segment (WT as above): input gradients accumulated into tensors that already hold another consumer's gradient */
+int smin_linear_rows_dx_acc(void* stream, const float* dy, int nseg, const float* WT, int R, int O, int K, float* const* dxs);
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */
 int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out);
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "smin_linear_rows_fwd": [_vp, _vp, _i] + [_vp] * 4 + [_i] * 4 + [_vp],
     "smin_linear_rows_bwd_workspace_bytes": [_i] * 3,
     "smin_linear_rows_bwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
+    "smin_linear_rows_dx_acc": [_vp, _vp, _i, _vp] + [_i] * 3 + [_vp],
     "smin_group_sum": [_vp, _vp, _i, _i, _i, _vp],
     "smin_video_encoder_fwd": [_vp] * 7 + [_i] * 4 + [_vp] * 2,
     "smin_video_encoder_bwd_workspace_bytes": [_i] * 4,

@@ -29,20 +29,26 @@ struct EpLinearRows {
             });
     }
 };
-struct EpStoreRows {
+template <bool ACC = false>
+struct EpStoreRows {                // out = acc (ACC: out += acc, the second and later consumers of one tensor's gradient)
     float* out;
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
-        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
+            float* o = out + (size_t)row * N + col;
+            stg4(o, ACC ? f4add(v, ldg4(o)) : v);
+        });
     }
 };
 
+template <bool ACC = false>
 struct EpSplitCols {                // column block s of the result goes to out[s] [rows][w]
     float* out[4]; int w;
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
         chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) {
             const int sg = (col >= w) + (col >= 2 * w) + (col >= 3 * w);
             float* q = sg == 0 ? out[0] : sg == 1 ? out[1] : sg == 2 ? out[2] : out[3];
-            stg4(q + (size_t)row * w + (col - sg * w), v);
+            float* o = q + (size_t)row * w + (col - sg * w);
+            stg4(o, ACC ? f4add(v, ldg4(o)) : v);
         });
     }
 };
@@ -117,9 +123,9 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
     int rc;
     if (dxs) {
         if (nseg == 1) {
-            rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows{dxs[0]}, R, K, O);
+            rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows<false>{dxs[0]}, R, K, O);
         } else {
-            EpSplitCols ep;
+            EpSplitCols<false> ep;
             for (int k = 0; k < 4; ++k) ep.out[k] = dxs[k < nseg ? k : 0];
             ep.w = K;
             rc = launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, ep, R, Kt, O);
@@ -135,6 +141,20 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
     if (rc) return rc;
     rc = launch_reduce_slabs2(st, slab, dW, O * Kt, bslab, dbias, O, sp); if (rc) return rc;
     return 0;
+}
+
+// dx_s += dy W_s for every segment: the input gradients of smin_linear_rows_bwd accumulated into tensors that already hold the
+// gradient of an earlier consumer (a separate full-size add per step otherwise)
+extern "C" int smin_linear_rows_dx_acc(void* stream, const float* dy, int nseg, const float* WT, int R, int O, int K, float* const* dxs)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && nseg >= 1 && nseg <= 4 && dxs != nullptr);
+    if (R == 0) return 0;
+    if (nseg == 1) return launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, EpStoreRows<true>{dxs[0]}, R, K, O);
+    EpSplitCols<true> ep;
+    for (int k = 0; k < 4; ++k) ep.out[k] = dxs[k < nseg ? k : 0];
+    ep.w = K;
+    return launch_gemm_nt(st, PlainMat{dy, O}, PlainMat{WT, O}, ep, R, nseg * K, O);
 }
 
 extern "C" int smin_group_sum(void* stream, const float* x, int groups, int C, int W, float* out)

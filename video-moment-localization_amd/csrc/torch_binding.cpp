@@ -1031,11 +1031,21 @@ struct SminCore : torch::autograd::Function<SminCore> {
             for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
                 const int nseg = i32(std::min<int64_t>(4, k - lo));
                 const float* xs[4]; float* dxs[4];
-                std::vector<Tensor> dx(nseg);
-                for (int sgm = 0; sgm < nseg; ++sgm) { xs[sgm] = fp(st.layer[lo + sgm].cc); dx[sgm] = at::empty({N * C, dl}, opt); dxs[sgm] = fpm(dx[sgm]); }
-                auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(i32(N * C), dl, nseg * dl), dev);
-                SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, fp(PcatT[k][part]), i32(N * C), dl, dl, dxs, nullptr, nullptr, ws.p, ws.n));
-                for (int sgm = 0; sgm < nseg; ++sgm) acc(dcc[lo + sgm], dx[sgm]);
+                // every earlier layer's attention output already has the gradient of the later layers (all of them, or none for the last
+                // layer): accumulate in the epilogue instead of a full-size add per tensor afterwards
+                const bool have = dcc[lo].defined();
+                for (int sgm = 0; sgm < nseg; ++sgm) {
+                    TORCH_CHECK(dcc[lo + sgm].defined() == have, "content stream: inconsistent gradient state of the attention outputs");
+                    xs[sgm] = fp(st.layer[lo + sgm].cc);
+                    if (!have) dcc[lo + sgm] = at::empty({N * C, dl}, opt);
+                    dxs[sgm] = fpm(dcc[lo + sgm]);
+                }
+                if (have) {
+                    SMIN_CK(smin_linear_rows_dx_acc(cur(), fp(dchat[k]), nseg, fp(PcatT[k][part]), i32(N * C), dl, dl, dxs));
+                } else {
+                    auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(i32(N * C), dl, nseg * dl), dev);
+                    SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, fp(PcatT[k][part]), i32(N * C), dl, dl, dxs, nullptr, nullptr, ws.p, ws.n));
+                }
             }
             if (k > 0) {
                 dhp = at::empty({N, dl}, opt);
