@@ -85,6 +85,9 @@ int smin_proposal_map_bwd(void* stream, const float* dfc, const float* dfm, cons
  * content stream's running sum; f_m also passes through to the moment unit's residual): dhbar / dres are HOST arrays of
  * n_dhbar (1..4) / n_dres (0..4) device pointers [N][D] whose sum is the gradient of hbar / is added to dfm. */
 int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar);
+/* the same, and hsum_out = hsum_in + hbar [N][D] (running sum over layers, read by the next layers' gate term of chat) */
+int smin_gate_fwd_sum(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar, const float* hsum_in,
+                      float* hsum_out);
 int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhbar, const float* const* dres, int n_dres,
                   const float* fm, const float* fs, const int32_t* row_ptr,
                   int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes);

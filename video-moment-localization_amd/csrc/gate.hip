@@ -8,16 +8,21 @@
 
 namespace smin {
 
+// SUM: also hsum_out = hsum_in + hbar (the running sum of the layers' gated features that the content stream's gate term reads;
+// a separate full-size add per layer otherwise)
+template <bool SUM>
 __global__ void gate_fwd_kernel(const float* __restrict__ fm, const float* __restrict__ fs, const int* __restrict__ cells,
-                                int N, int D4, float* __restrict__ hbar)
+                                int N, int D4, float* __restrict__ hbar, const float* __restrict__ hsum_in, float* __restrict__ hsum_out)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * D4) return;
     const size_t n = idx / D4; const int d4 = (int)(idx % D4);
     const int b = cells[4 * n];
     const float4 x = ldg4(fm + idx * 4), s = ldg4(fs + ((size_t)b * D4 + d4) * 4);
-    stg4(hbar + idx * 4, make_float4(x.x / (1.0f + expf(-x.x * s.x)), x.y / (1.0f + expf(-x.y * s.y)),
-                                     x.z / (1.0f + expf(-x.z * s.z)), x.w / (1.0f + expf(-x.w * s.w))));
+    const float4 h = make_float4(x.x / (1.0f + expf(-x.x * s.x)), x.y / (1.0f + expf(-x.y * s.y)),
+                                 x.z / (1.0f + expf(-x.z * s.z)), x.w / (1.0f + expf(-x.w * s.w)));
+    stg4(hbar + idx * 4, h);
+    if (SUM) stg4(hsum_out + idx * 4, f4add(ldg4(hsum_in + idx * 4), h));
 }
 
 // dfm = dh * (g + fm*g*(1-g)*fs) ; partial[b][chunk][:] = sum over the chunk's cells of dh * fm^2 * g*(1-g)
@@ -98,7 +103,20 @@ extern "C" int smin_gate_fwd(void* stream, const float* fm, const float* fs, con
     SMIN_REQUIRE(D % 4 == 0);
     if (N == 0) return 0;
     const size_t tot = (size_t)N * (D / 4);
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, fs, cells, N, D / 4, hbar);
+    hipLaunchKernelGGL(gate_fwd_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, fs, cells, N, D / 4, hbar,
+                       (const float*)nullptr, (float*)nullptr);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_gate_fwd_sum(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar, const float* hsum_in,
+                                 float* hsum_out)
+{
+    SMIN_REQUIRE(D % 4 == 0 && hsum_in != nullptr && hsum_out != nullptr);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (D / 4);
+    hipLaunchKernelGGL(gate_fwd_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fm, fs, cells, N, D / 4, hbar, hsum_in,
+                       hsum_out);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

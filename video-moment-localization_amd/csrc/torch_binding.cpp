@@ -840,7 +840,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
             const bool lastl = k == nl - 1;
             ls.fm = fm; ls.fb = fb;
             ls.hbar = at::empty_like(fm);
-            SMIN_CK(smin_gate_fwd(cur(), fp(fm), fp(fs), ip(cells), n, D, fpm(ls.hbar)));
+            ls.Hs = Hs;                                                            // sum of the earlier layers' gated features (undefined for k = 0)
+            if (k > 0 && !lastl && N > 0) {                                        // the next layers' running sum comes out of the same pass
+                Tensor Hs_next = at::empty_like(fm);
+                SMIN_CK(smin_gate_fwd_sum(cur(), fp(fm), fp(fs), ip(cells), n, D, fpm(ls.hbar), fp(Hs), fpm(Hs_next)));
+                Hs = Hs_next;
+            } else {
+                SMIN_CK(smin_gate_fwd(cur(), fp(fm), fp(fs), ip(cells), n, D, fpm(ls.hbar)));
+                if (!lastl) Hs = Hs.defined() ? Hs + ls.hbar : ls.hbar;
+            }
             // boundary unit on the second stream beside the content stream; joins before the moment unit
             wait_stream(side, curs);
             {
@@ -853,12 +861,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
             }
             // chat_k = clip-window term + [cc_0 | ..] Pcat^T + const_k + (Hs Wch^T per cell)
             Tensor chat = pgs[k];
-            ls.Hs = Hs;
+            const Tensor& Hs_k = ls.Hs;
             for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
                 Tensor hp;
                 if (lo == 0) {
                     hp = at::empty({N, dl}, opt);
-                    const float* xs[1] = {fp(Hs)};
+                    const float* xs[1] = {fp(Hs_k)};
                     SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_CH_W)), nullptr, nullptr, nullptr, 1, n, dl, D, fpm(hp)));
                 }
                 const int nseg = i32(std::min<int64_t>(4, k - lo));
@@ -878,7 +886,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 const float* xs[1] = {fp(ls.ccmean)};
                 SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_C_W)), fp(lp(k, L_C_B)), fp(cumean), fp(ls.hbar), 1, n, D, dl, fpm(ls.cum)));
             }
-            if (!lastl) Hs = Hs.defined() ? Hs + ls.hbar : ls.hbar;
             wait_stream(curs, side);
             ls.x1 = at::empty_like(fm);                                            // f_b[i] * f_b[j], kept for the weight gradient
             Tensor mu = at::empty_like(fm);
