@@ -1151,11 +1151,8 @@ struct SminCore : torch::autograd::Function<SminCore> {
             SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
                                                tab.second.data_ptr()));
             if (prep_kernel) at::sum_out(dconsts[0], dchat[0], at::IntArrayRef{0}); else dconsts[0] = dchat[0].sum(0);
-            Tensor df1 = at::empty({B, T, D}, opt);
             keep.push_back(dg);
-            const float* xs[1] = {fp(f)}; float* dxs[1] = {fpm(df1)};
-            auto ws2 = scratch(smin_linear_rows_bwd_workspace_bytes(i32(B * T), i32(nl * dl), D), dev);
-            SMIN_CK(smin_linear_rows_bwd(cur(), fp(dg), xs, 1, fp(Wch_allT), i32(B * T), i32(nl * dl), D, dxs, nullptr, nullptr, ws2.p, ws2.n));
+            const float* xs[1] = {fp(f)};
             wait_stream(wstr, curs);
             {
                 StreamScope sc(wstr);
@@ -1165,11 +1162,14 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 if (!prep_kernel) for (int64_t k = 0; k < nl; ++k) acc(dlp(k, L_CH_W), dWch_all.slice(0, k * dl, (k + 1) * dl));
             }
             weights_done = mark(wstr);
+            // df = gradient through the proposal map (f_m, f_b) + gradient through the clip-window terms, the second accumulated by its
+            // contraction's epilogue
             df = at::empty({B, T, D}, opt);
             auto ws3 = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
             SMIN_CK(smin_proposal_map_bwd(cur(), nullptr, fp(dfm), fp(dfb_next), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, D, fpm(df), ws3.p, ws3.n, ip(tab.first),
                                           tab.second.data_ptr()));
-            df.add_(df1);
+            float* dxs[1] = {fpm(df)};
+            SMIN_CK(smin_linear_rows_dx_acc(cur(), fp(dg), 1, fp(Wch_allT), i32(B * T), i32(nl * dl), D, dxs));
         }
 
         // ---- parameter products on the second stream: consts_k = b_ch_k + Wch_k bsum_k (bsum_k = sum_{l<k} b_c_l), Pcat_k = [Wch_k Wc_l]_l
