@@ -226,6 +226,39 @@ __global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int N
     Hprev[idx] = (q >= 0 && q < Nq) ? Hout[((size_t)b * Nq + q) * 2 * H + d * H + u] : 0.f;
 }
 
+
+// The operand layouts of the layer kernels from nn.LSTM's eight parameter tensors of a layer, in one launch (as torch calls: two
+// concatenations, two additions, a stack and a permuted copy per layer, ahead of the first kernel of the step's critical path):
+//   Wih [8H][In] = [w_ih; w_ih_reverse],  bias [8H] = [b_ih + b_hh; b_ih_reverse + b_hh_reverse],
+//   Whh [2][4H][H] = {w_hh, w_hh_reverse},  W4 [2][H][H][4] with W4[d][k][u][g] = w_hh_d[g H + u][k]
+struct LstmRaw { const float* w[8]; };              // w_ih, w_hh, b_ih, b_hh, then the same four of the reverse direction
+__global__ void lstm_pack_kernel(LstmRaw R, int In, int H, float* __restrict__ Wih, float* __restrict__ bias, float* __restrict__ Whh,
+                                 float* __restrict__ W4)
+{
+    const size_t nWih = (size_t)8 * H * In, nB = (size_t)8 * H, nWhh = (size_t)2 * 4 * H * H;
+    const size_t tot = nWih + nB + 2 * nWhh;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        if (e < nWih) {
+            const size_t half = (size_t)4 * H * In;
+            Wih[e] = e < half ? R.w[0][e] : R.w[4][e - half];
+        } else if (e < nWih + nB) {
+            const size_t j = e - nWih;
+            const int dir = j >= (size_t)4 * H;
+            const size_t jj = j - (size_t)dir * 4 * H;
+            bias[j] = R.w[dir * 4 + 2][jj] + R.w[dir * 4 + 3][jj];
+        } else if (e < nWih + nB + nWhh) {
+            const size_t j = e - nWih - nB, half = (size_t)4 * H * H;
+            Whh[j] = j < half ? R.w[1][j] : R.w[5][j - half];
+        } else {
+            const size_t j = e - nWih - nB - nWhh;                  // W4 index ((d H + k) H + u) 4 + g
+            const int g = (int)(j & 3);
+            const size_t r = j >> 2;
+            const int u = (int)(r % H), k = (int)((r / H) % H), d = (int)(r / ((size_t)H * H));
+            W4[j] = R.w[d * 4 + 1][((size_t)g * H + u) * H + k];
+        }
+    }
+}
+
 }  // namespace smin
 
 using namespace smin;
@@ -242,6 +275,16 @@ extern "C" int smin_bilstm_layer_fwd(void* stream, const float* X, const float* 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, G, W4, len, B, Nq, H, Hout, Cs);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_lstm_pack(void* stream, const float* const* w, int In, int H, float* Wih, float* bias, float* Whh, float* W4)
+{
+    SMIN_REQUIRE(In >= 1 && H >= 1);
+    LstmRaw R;
+    for (int q = 0; q < 8; ++q) { SMIN_REQUIRE(w[q] != nullptr); R.w[q] = w[q]; }
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, R, In, H, Wih, bias, Whh, W4);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

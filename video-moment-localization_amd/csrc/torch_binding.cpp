@@ -762,10 +762,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
             LstmState& ls = st.lstm[layer];
             const int In = i32(x.size(2)), Hh = i32(H);
             ls.x = x;
-            ls.Wih = at::cat({w[0], w[4]});                                        // [8H, In]
-            Tensor bias = at::cat({w[2] + w[3], w[6] + w[7]});                     // [8H]
-            ls.Whh = at::stack({w[1], w[5]});                                      // [2, 4H, H]
-            Tensor W4 = ls.Whh.view({2, 4, H, H}).permute({0, 3, 2, 1}).contiguous();   // [2, k, u, gate]
+            ls.Wih = at::empty({8 * H, (int64_t)In}, opt);                         // [w_ih; w_ih_reverse]
+            Tensor bias = at::empty({8 * H}, opt);                                 // b_ih + b_hh per direction
+            ls.Whh = at::empty({2, 4 * H, H}, opt);
+            Tensor W4 = at::empty({2, H, H, 4}, opt);                              // [d, k, u, gate]
+            {
+                const float* raw[8];
+                for (int q = 0; q < 8; ++q) raw[q] = fp(w[q]);
+                SMIN_CK(smin_lstm_pack(cur(), raw, In, Hh, fpm(ls.Wih), fpm(bias), fpm(ls.Whh), fpm(W4)));
+            }
             ls.G = at::empty({Bq, Nq_in, 2, 4 * H}, opt); ls.Hout = at::empty({Bq, Nq_in, 2 * H}, opt); ls.Cs = at::empty({Bq, Nq_in, 2, H}, opt);
             SMIN_CK(smin_bilstm_layer_fwd(cur(), fp(x), fp(ls.Wih), fp(bias), fp(W4), ip(st.len32), B, i32(Nq_in), In, Hh, fpm(ls.G), fpm(ls.Hout), fpm(ls.Cs)));
             x = ls.Hout;
