@@ -289,6 +289,10 @@ int smin_video_encoder_bwd(void* stream, const float* df, const float* fv, const
  * direction; W4 [2][H][H][4] with W4[d][k][u][g] = W_hh_d[g*H+u][k]; len [B] valid lengths (device).  Outputs: Hout
  * [B][Nq][2H] (zero at padded positions, as pad_packed_sequence gives), and for backward G [B][Nq][2][4H] (gate
  * activations i,f,g,o) and Cs [B][Nq][2][H] (cell states).  Requires In % 4 == 0, H % 4 == 0, H <= 256. */
+/* sentence feature (models.py:60-62): fs [B][2H], fs[b] = [fw[b][len_b - 1][0:H] | fw[b][0][H:2H]] with fw [B][Nq][2H] (len clamped to
+ * 1..Nq); backward adds dfs into the same entries of dfw (in place) */
+int smin_sentence_feature_fwd(void* stream, const float* fw, const int32_t* len, int B, int Nq, int H, float* fs);
+int smin_sentence_feature_bwd(void* stream, const float* dfs, const int32_t* len, int B, int Nq, int H, float* dfw);
 /* the operand layouts above from nn.LSTM's eight parameter tensors of a layer (w: HOST array of 8 device pointers: weight_ih, weight_hh,
  * bias_ih, bias_hh of the forward direction, then of the reverse direction), one launch; also writes Whh [2][4H][H] for the backward call */
 int smin_lstm_pack(void* stream, const float* const* w, int In, int H, float* Wih, float* bias, float* Whh, float* W4);

@@ -259,6 +259,26 @@ __global__ void lstm_pack_kernel(LstmRaw R, int In, int H, float* __restrict__ W
     }
 }
 
+
+// Sentence feature of the query encoder (models.py:60-62): f_s[b] = [h_fwd at the last word | h_bwd at the first word]
+//   fs[b][d] = d < H ? fw[b][max(len_b - 1, 0)][d] : fw[b][0][d];   backward: the same entries of dfw += dfs
+__global__ void sentence_feature_kernel(const float* __restrict__ fw, const int* __restrict__ len, int B, int Nq, int H, float* __restrict__ fs)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 2 * H) return;
+    const int b = idx / (2 * H), d = idx % (2 * H);
+    const int p = d < H ? max(min(len[b], Nq) - 1, 0) : 0;
+    fs[idx] = fw[((size_t)b * Nq + p) * 2 * H + d];
+}
+__global__ void sentence_feature_bwd_kernel(const float* __restrict__ dfs, const int* __restrict__ len, int B, int Nq, int H, float* __restrict__ dfw)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 2 * H) return;
+    const int b = idx / (2 * H), d = idx % (2 * H);
+    const int p = d < H ? max(min(len[b], Nq) - 1, 0) : 0;
+    dfw[((size_t)b * Nq + p) * 2 * H + d] += dfs[idx];             // one writer per entry
+}
+
 }  // namespace smin
 
 using namespace smin;
@@ -275,6 +295,21 @@ extern "C" int smin_bilstm_layer_fwd(void* stream, const float* X, const float* 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, G, W4, len, B, Nq, H, Hout, Cs);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int smin_sentence_feature_fwd(void* stream, const float* fw, const int32_t* len, int B, int Nq, int H, float* fs)
+{
+    SMIN_REQUIRE(B >= 1 && Nq >= 1 && H >= 1);
+    hipLaunchKernelGGL(sentence_feature_kernel, dim3(cdiv(B * 2 * H, 256)), dim3(256), 0, (hipStream_t)stream, fw, len, B, Nq, H, fs);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int smin_sentence_feature_bwd(void* stream, const float* dfs, const int32_t* len, int B, int Nq, int H, float* dfw)
+{
+    SMIN_REQUIRE(B >= 1 && Nq >= 1 && H >= 1);
+    hipLaunchKernelGGL(sentence_feature_bwd_kernel, dim3(cdiv(B * 2 * H, 256)), dim3(256), 0, (hipStream_t)stream, dfs, len, B, Nq, H, dfw);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

@@ -778,8 +778,8 @@ struct SminCore : torch::autograd::Function<SminCore> {
         Tensor fw = x;
         if (Nq_in < maxq) fw = at::constant_pad_nd(fw, {0, 0, 0, maxq - Nq_in}, 0);
         fw = fw.contiguous();
-        st.last = (length.to(at::kLong) - 1).clamp_min(0).view({Bq, 1, 1}).expand({Bq, 1, H}).contiguous();
-        Tensor fs = at::cat({fw.slice(2, 0, H).gather(1, st.last).view({Bq, H}), fw.select(1, 0).slice(1, H)}, 1);
+        Tensor fs = at::empty({Bq, 2 * H}, opt);                                    // [h_fwd at the last word | h_bwd at the first word]
+        SMIN_CK(smin_sentence_feature_fwd(cur(), fp(fw), ip(st.len32), B, i32(fw.size(1)), i32(H), fpm(fs)));
         st.vx = cont(video_features); st.vmaskf = cont(fl(video_mask.reshape({Bq * Tn})));
         st.fv = at::empty({Bq, T, (int64_t)D}, opt);
         Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
@@ -1232,8 +1232,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             if (tail != curs) await(curs, words_done);
             Tensor dfs_total = sum_list(dfs_parts), dfw_total = sum_list(dfw_parts);
             // f_s = [f_w[b, len_b - 1, :H] | f_w[b, 0, H:]] (models.py:60-62)
-            dfw_total.slice(2, 0, H).scatter_add_(1, st.last, dfs_total.slice(1, 0, H).unsqueeze(1));
-            dfw_total.select(1, 0).slice(1, H).add_(dfs_total.slice(1, H));
+            SMIN_CK(smin_sentence_feature_bwd(cur(), fp(dfs_total), ip(st.len32), B, Nq, i32(H), fpm(dfw_total)));
             Tensor dH = Nq_in < Nq ? dfw_total.slice(1, 0, Nq_in).contiguous() : dfw_total;
             for (int layer = 1; layer >= 0; --layer) {
                 LstmState& ls = st.lstm[layer];
