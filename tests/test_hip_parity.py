@@ -902,6 +902,34 @@ def test_step_helpers_through_the_c_abi(dev):
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
 
 
+def test_short_query_batch_is_padded_to_max_query_length(dev):
+    """A batch whose longest query has fewer words than max_query_length (the reference pads f_w to max_query_length, models.py:58-59):
+    the one-node step (library kernels for the sentence feature and its gradient) against the Python host."""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 64, 16, 4, 128, 32, 3, 40, 12, 64, 4
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    batch = O.synthetic_batch(B, T, L, Nq, Din, seed=8)
+    short = 8
+    batch["query_features"] = batch["query_features"][:, :short].contiguous()
+    batch["query_mask"] = batch["query_mask"][:, :short].contiguous()
+    batch["query_mask"][0] = 1                                  # one query of full (short) length, the others as generated
+    b = {k: v.to(dev) for k, v in batch.items()}
+    res = []
+    for native in (True, False):
+        m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+        m.native_host = native
+        out = m(*H.model_inputs(b))
+        loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+        res.append(([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (o0, g0), (o1, g1) = res
+    for x, y in zip(o0, o1):
+        assert float((x - y).abs().max()) <= 1e-5             # (the two hosts form the weight products with different kernels)
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for k in g1:
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 1e-6 * gmax + 1e-9, k
+
+
 @pytest.mark.parametrize("nl,D,dl", [(3, 512, 128), (1, 64, 32), (6, 96, 32), (8, 64, 64)])
 def test_param_prep_kernels(dev, nl, D, dl):
     """csrc/param_prep.hip (every layer's parameter-only operands of the content stream and the moment unit in one launch per
