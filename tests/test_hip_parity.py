@@ -927,7 +927,7 @@ def test_short_query_batch_is_padded_to_max_query_length(dev):
         assert float((x - y).abs().max()) <= 1e-5             # (the two hosts form the weight products with different kernels)
     gmax = max(float(v.abs().max()) for v in g1.values())
     for k in g1:
-        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 1e-6 * gmax + 1e-9, k
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 3e-6 * gmax + 1e-9, k     # (some gradients are zero in exact arithmetic)
 
 
 @pytest.mark.parametrize("nl,D,dl", [(3, 512, 128), (1, 64, 32), (6, 96, 32), (8, 64, 64)])
