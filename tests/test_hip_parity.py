@@ -902,18 +902,23 @@ def test_step_helpers_through_the_c_abi(dev):
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
 
 
-def test_short_query_batch_is_padded_to_max_query_length(dev):
+@pytest.mark.parametrize("cut", [False, True])
+def test_short_query_batch_is_padded_to_max_query_length(dev, cut):
     """A batch whose longest query has fewer words than max_query_length (the reference pads f_w to max_query_length, models.py:58-59):
-    the one-node step (library kernels for the sentence feature and its gradient) against the Python host."""
+    the one-node step (library kernels for the sentence feature and its gradient) against the Python host.  cut=False is the reference's
+    case (the dataset pads tokens and mask to max_query_length, dataset.py:35, 173); cut=True hands over the batch cut to its longest query,
+    which both hosts pad themselves."""
     from oracle import smin_oracle as O
     from vml_amd import loss_fn
     T, L, C, D, dl, layers, Din, Nq, Hh, B = 64, 16, 4, 128, 32, 3, 40, 12, 64, 4
     sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
     batch = O.synthetic_batch(B, T, L, Nq, Din, seed=8)
     short = 8
-    batch["query_features"] = batch["query_features"][:, :short].contiguous()
-    batch["query_mask"] = batch["query_mask"][:, :short].contiguous()
-    batch["query_mask"][0] = 1                                  # one query of full (short) length, the others as generated
+    batch["query_mask"][:, short:] = 0
+    batch["query_mask"][0, :short] = 1                          # one query of full (short) length, the others as generated
+    if cut:
+        batch["query_features"] = batch["query_features"][:, :short].contiguous()
+        batch["query_mask"] = batch["query_mask"][:, :short].contiguous()
     b = {k: v.to(dev) for k, v in batch.items()}
     res = []
     for native in (True, False):
@@ -925,6 +930,12 @@ def test_short_query_batch_is_padded_to_max_query_length(dev):
     (o0, g0), (o1, g1) = res
     for x, y in zip(o0, o1):
         assert float((x - y).abs().max()) <= 1e-5             # (the two hosts form the weight products with different kernels)
+    if cut:                                                   # the oracle (like the reference) wants the mask as wide as the padded f_w
+        batch["query_features"] = torch.nn.functional.pad(batch["query_features"], (0, 0, 0, Nq - short))
+        batch["query_mask"] = torch.nn.functional.pad(batch["query_mask"], (0, 0, 0, Nq - short))
+    ref = O.smin_forward({k: v.clone() for k, v in sd.items()}, dict(T=T, L=L, C=C), *H.model_inputs(batch))
+    for x, y in zip(o0, ref):
+        assert (x.cpu() - y).abs().max().item() < SCORE_TOL
     gmax = max(float(v.abs().max()) for v in g1.values())
     for k in g1:
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 3e-6 * gmax + 1e-9, k     # (some gradients are zero in exact arithmetic)

@@ -1262,9 +1262,16 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
 struct Words { Tensor Mq, uq, what, shat; };
 
-std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_features, const Tensor& video_mask, const Tensor& query_features, const Tensor& query_mask,
+std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_features, const Tensor& video_mask, const Tensor& query_features, const Tensor& query_mask_in,
                                                         const Tensor& length_mask, const Tensor& moment_mask, at::TensorList prm, at::IntArrayRef cfg)
 {
+    // The reference's dataset pads queries and their mask to max_query_length (dataset.py:35, 173); a batch cut to its longest query is
+    // taken too: the word features are padded below as models.py:58-59 does, and the mask here, since every kernel reads max_query_length columns.
+    TORCH_CHECK(cfg.size() >= 10 && query_features.dim() == 3, "smin_forward: query_features (B, words, dim) and cfg of at least 10 entries");
+    Tensor query_mask = query_mask_in.reshape({query_features.size(0), -1});
+    TORCH_CHECK((query_mask.size(1) == query_features.size(1) || query_mask.size(1) == cfg[6]) && query_features.size(1) <= cfg[6], "smin_forward: query_mask has ", query_mask.size(1),
+                " columns for ", query_features.size(1), " words (max_query_length ", cfg[6], ")");
+    if (query_mask.size(1) < cfg[6]) query_mask = at::constant_pad_nd(query_mask, {0, cfg[6] - query_mask.size(1)}, 0);
     TORCH_CHECK(video_features.is_cuda(), "smin_forward runs on a HIP device only (there is no CPU fallback)");
     TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core)]");
     const int64_t T = cfg[0], L = cfg[1], C = cfg[2], D = cfg[3], nl = cfg[5], maxq = cfg[6], H = cfg[7];

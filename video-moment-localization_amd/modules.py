@@ -560,6 +560,13 @@ class SMIN(nn.Module):
 
     @_hip_forward
     def forward(self, video_features, video_mask, query_features, query_mask, length_mask, moment_mask):
+        # the reference's dataset pads queries and their mask to max_query_length (dataset.py:35, 173); a batch cut to its longest query is taken
+        # too: the encoder pads f_w as models.py:58-59 does, and the mask is padded here (every kernel reads max_query_length mask columns)
+        query_mask = query_mask.reshape(query_features.shape[0], -1)
+        if query_mask.shape[1] != query_features.shape[1] or query_mask.shape[1] > self.max_query_length:
+            raise ValueError(f"query_mask has {query_mask.shape[1]} columns for {query_features.shape[1]} words (max_query_length {self.max_query_length})")
+        if query_mask.shape[1] < self.max_query_length:
+            query_mask = torch.nn.functional.pad(query_mask, (0, self.max_query_length - query_mask.shape[1]))
         if self._native_ok(video_features, query_features):
             from . import _lib
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
