@@ -280,7 +280,8 @@ int smin_word_prep_bwd(void* stream, const float* const* dwhat, const float* con
 int smin_video_encoder_fwd(void* stream, const float* x, const float* W, const float* bias, const float* pe, const float* vmask,
                            const float* fs, int B, int T, int Din, int D, float* fv, float* f);
 size_t smin_video_encoder_bwd_workspace_bytes(int B, int T, int Din, int D);
-/* df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D] */
+/* df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D].  May be issued as two calls on the same ws (e.g. on two streams, the
+ * second ordered behind the first): dW == NULL -> inputs half (dfs; the masked gradient stays in ws); df == NULL -> weights half. */
 int smin_video_encoder_bwd(void* stream, const float* df, const float* fv, const float* fs, const float* vmask, const float* x,
                            int B, int T, int Din, int D, float* dW, float* dbias, float* dpe, float* dfs, void* ws, size_t ws_bytes);
 
@@ -300,7 +301,8 @@ int smin_bilstm_layer_fwd(void* stream, const float* X, const float* Wih_cat, co
                           const int32_t* len, int B, int Nq, int In, int H, float* G, float* Hout, float* Cs);
 size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H);
 /* dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H] (= d b_ih = d b_hh),
- * dWhh [2][4H][H].  Wih_catT [In][8H]; Whh [2][4H][H] (W_hh per direction, as nn.LSTM stores it). */
+ * dWhh [2][4H][H].  Wih_catT [In][8H]; Whh [2][4H][H] (W_hh per direction, as nn.LSTM stores it).  May be issued as two calls on the
+ * same ws: dWih_cat == NULL -> inputs half (the recurrence and dX; gate gradients stay in ws); dHout == NULL -> weights half. */
 int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
                           const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);

@@ -289,6 +289,14 @@ def test_native_host_equals_python_host(dev):
         loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
         for k, p in m.named_parameters():
             assert torch.equal(p.grad, g0[k]), k
+        # ... and where its weight-side work is queued (weight stream or main stream) changes no bit
+        for async_weights in (False,):
+            m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+            m.async_weights = async_weights
+            out = m(*H.model_inputs(b))
+            loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+            for k, p in m.named_parameters():
+                assert torch.equal(p.grad, g0[k]), (k, async_weights)
 
 
 def test_target_kernel_and_feeder(dev):
@@ -900,6 +908,54 @@ def test_step_helpers_through_the_c_abi(dev):
     assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])
     assert (full[2].double() - dy.double().t() @ torch.cat([xa, xb], 1).double()).abs().max().item() < 1e-3
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
+    # video encoder and LSTM layer backward: inputs half, then weights half on the same workspace (the step runs the second on its weight stream)
+    B, T, Din, D = 3, 50, 24, 64
+    df, fv, fs, x = r(B * T, D), r(B * T, D), r(B, D), r(B * T, Din)
+    vm = (torch.rand(B * T, generator=g) > 0.2).float().to(dev)
+    nbv = lib.smin_video_encoder_bwd_workspace_bytes(B, T, Din, D)
+
+    def ve_bwd(split):
+        ws = torch.zeros(nbv + 64, dtype=torch.uint8, device=dev)
+        dW, db, dpe, dfs = torch.full((D, Din), 7.0, device=dev), torch.full((D,), 7.0, device=dev), torch.full((T, D), 7.0, device=dev), torch.full((B, D), 7.0, device=dev)
+        if split:
+            call("smin_video_encoder_bwd", stream(), ptr(df), ptr(fv), ptr(fs), ptr(vm), ptr(x), B, T, Din, D, None, None, None, ptr(dfs), ptr(ws), ws.numel())
+            assert float(dW.min()) == 7.0 and float(dpe.min()) == 7.0
+            call("smin_video_encoder_bwd", stream(), None, ptr(fv), ptr(fs), ptr(vm), ptr(x), B, T, Din, D, ptr(dW), ptr(db), ptr(dpe), None, ptr(ws), ws.numel())
+        else:
+            call("smin_video_encoder_bwd", stream(), ptr(df), ptr(fv), ptr(fs), ptr(vm), ptr(x), B, T, Din, D, ptr(dW), ptr(db), ptr(dpe), ptr(dfs), ptr(ws), ws.numel())
+        return dW, db, dpe, dfs
+    for a, b in zip(ve_bwd(False), ve_bwd(True)):
+        assert torch.equal(a, b)
+    dv = df.view(B, T, D) * fs.view(B, 1, D) * vm.view(B, T, 1)
+    full = ve_bwd(False)
+    assert (full[3].double() - (df * fv).view(B, T, D).double().sum(1)).abs().max().item() < 1e-4
+    assert (full[0].double() - dv.view(B * T, D).double().t() @ x.double()).abs().max().item() < 1e-3
+    assert (full[2].double() - dv.double().sum(0)).abs().max().item() < 1e-4
+    wsn = torch.zeros(nbv + 64, dtype=torch.uint8, device=dev)
+    assert lib.smin_video_encoder_bwd(stream(), None, ptr(fv), ptr(fs), ptr(vm), ptr(x), B, T, Din, D, None, None, None, None, ptr(wsn), wsn.numel()) < 0     # neither half
+    B, Nq, In, Hh = 5, 7, 24, 32
+    xq, dHo = r(B, Nq, In), r(B, Nq, 2 * Hh)
+    Wih, bias, Whh = r(8 * Hh, In) * 0.3, r(8 * Hh) * 0.1, r(2, 4 * Hh, Hh) * 0.3
+    W4 = Whh.view(2, 4, Hh, Hh).permute(0, 3, 2, 1).contiguous()
+    length = torch.tensor([7, 3, 1, 5, 7], dtype=torch.int32, device=dev)
+    G, Ho, Cs = torch.empty(B, Nq, 2, 4 * Hh, device=dev), torch.empty(B, Nq, 2 * Hh, device=dev), torch.empty(B, Nq, 2, Hh, device=dev)
+    call("smin_bilstm_layer_fwd", stream(), ptr(xq), ptr(Wih), ptr(bias), ptr(W4), ptr(length), B, Nq, In, Hh, ptr(G), ptr(Ho), ptr(Cs))
+    WihT = Wih.t().contiguous()
+    nbl2 = lib.smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, Hh)
+
+    def lstm_bwd(split):
+        ws = torch.zeros(nbl2 + 64, dtype=torch.uint8, device=dev)
+        dX, dWih, dbi, dWhh = torch.full((B, Nq, In), 7.0, device=dev), torch.full((8 * Hh, In), 7.0, device=dev), torch.full((8 * Hh,), 7.0, device=dev), torch.full((2, 4 * Hh, Hh), 7.0, device=dev)
+        args = (ptr(xq), ptr(Ho), ptr(G), ptr(Cs), ptr(WihT), ptr(Whh), ptr(length), B, Nq, In, Hh)
+        if split:
+            call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), None, None, None, ptr(ws), ws.numel())
+            assert float(dWih.min()) == 7.0 and float(dWhh.min()) == 7.0
+            call("smin_bilstm_layer_bwd", stream(), None, *args, None, ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
+        else:
+            call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
+        return dX, dWih, dbi, dWhh
+    for a, b in zip(lstm_bwd(False), lstm_bwd(True)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("cut", [False, True])

@@ -331,7 +331,9 @@ extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, i
     return sizeof(float) * ((size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + sp2 * (size_t)4 * H * H + 256);
 }
 
-// dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H]
+// dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H].
+// In two calls on the same ws: dWih_cat == NULL -> the inputs half (recurrence and dX; the gate gradients stay in ws);
+// dHout == NULL -> the weights half (dWih_cat, dbias_cat, dWhh from the gate gradients in ws).
 extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
                                      const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                                      float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes)
@@ -349,13 +351,17 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
     SMIN_REQUIRE(H4 % 16 == 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
-    SMIN_LAUNCH_CHECK();
+    SMIN_REQUIRE(dHout != nullptr || dWih_cat != nullptr);
     int rc;
-    if (dX) {
-        rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
-        if (rc) return rc;
+    if (dHout) {                                                       // inputs half: the recurrence (gate gradients stay in ws), dX
+        hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
+        SMIN_LAUNCH_CHECK();
+        if (dX) {
+            rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
+            if (rc) return rc;
+        }
     }
+    if (!dWih_cat) return 0;
     const int sp1 = tn_splits(R, H8, In);
     float* bslab = slab + (size_t)sp1 * H8 * In;
     rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;

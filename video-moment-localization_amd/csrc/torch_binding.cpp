@@ -1225,23 +1225,44 @@ struct SminCore : torch::autograd::Function<SminCore> {
             Tensor dfs_video = at::empty_like(fs);
             dbb[P_VE_W] = at::empty({D, Din}, opt); dbb[P_VE_B] = at::empty({D}, opt);
             dbb[P_PE] = pe_rows != T ? at::zeros({pe_rows, D}, opt) : at::empty({T, D}, opt);
-            auto ws = scratch(smin_video_encoder_bwd_workspace_bytes(B, Ti, Din, D), dev);
-            SMIN_CK(smin_video_encoder_bwd(cur(), fp(df), fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, fpm(dbb[P_VE_W]), fpm(dbb[P_VE_B]), fpm(dbb[P_PE]),
-                                           fpm(dfs_video), ws.p, ws.n));
+            // every call below is split into its inputs half (main stream, the dependent chain) and its weights half (weight stream); the
+            // intermediate of a pair lives in a buffer of its own (the per-stream scratch is reused by the next call on that stream)
+            auto own = [&](size_t nbytes) {
+                Tensor t = at::empty({(int64_t)nbytes + 256}, at::TensorOptions().dtype(at::kByte).device(dev));
+                keep.push_back(t);
+                return t;
+            };
+            Tensor wsv = own(smin_video_encoder_bwd_workspace_bytes(B, Ti, Din, D));
+            SMIN_CK(smin_video_encoder_bwd(cur(), fp(df), fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, nullptr, nullptr, nullptr, fpm(dfs_video), wsv.data_ptr(),
+                                           (size_t)wsv.numel()));
             dfs_parts.push_back(dfs_video);
             if (tail != curs) await(curs, words_done);
             Tensor dfs_total = sum_list(dfs_parts), dfw_total = sum_list(dfw_parts);
             // f_s = [f_w[b, len_b - 1, :H] | f_w[b, 0, H:]] (models.py:60-62)
             SMIN_CK(smin_sentence_feature_bwd(cur(), fp(dfs_total), ip(st.len32), B, Nq, i32(H), fpm(dfw_total)));
             Tensor dH = Nq_in < Nq ? dfw_total.slice(1, 0, Nq_in).contiguous() : dfw_total;
+            keep.push_back(dfs_total); keep.push_back(dfw_total); keep.push_back(dH); keep.push_back(df);
+            wait_stream(wstr, curs);
+            {
+                StreamScope sc(wstr);
+                SMIN_CK(smin_video_encoder_bwd(cur(), nullptr, fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, fpm(dbb[P_VE_W]), fpm(dbb[P_VE_B]), fpm(dbb[P_PE]),
+                                               nullptr, wsv.data_ptr(), (size_t)wsv.numel()));
+            }
             for (int layer = 1; layer >= 0; --layer) {
                 LstmState& ls = st.lstm[layer];
                 const int In = i32(ls.x.size(2)), Hh = i32(H);
                 Tensor dX = layer > 0 ? at::empty_like(ls.x) : Tensor();
                 Tensor dWih = at::empty_like(ls.Wih), dbias = at::empty({8 * H}, opt), dWhh = at::empty_like(ls.Whh);
-                auto wsl = scratch(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh), dev);
+                Tensor wsl = own(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh));
                 SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
-                                              fpm(dX), fpm(dWih), fpm(dbias), fpm(dWhh), wsl.p, wsl.n));
+                                              fpm(dX), nullptr, nullptr, nullptr, wsl.data_ptr(), (size_t)wsl.numel()));
+                wait_stream(wstr, curs);
+                {
+                    StreamScope sc(wstr);
+                    SMIN_CK(smin_bilstm_layer_bwd(cur(), nullptr, fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
+                                                  nullptr, fpm(dWih), fpm(dbias), fpm(dWhh), wsl.data_ptr(), (size_t)wsl.numel()));
+                }
+                if (dX.defined()) keep.push_back(dX);
                 const int64_t H4 = 4 * H;
                 Tensor* o = &dbb[P_LSTM + 8 * layer];
                 Tensor db_f = dbias.slice(0, 0, H4), db_r = dbias.slice(0, H4);

@@ -21,21 +21,33 @@ struct EpVideoEnc {                 // row = b*T + t
     }
 };
 
-// dv[b][t][:] = df * fs[b] * vmask[b][t] ;  dfs[b][:] = sum_t df[b][t][:] * fv[b][t][:]        grid (D/4 / 64, B), 64 threads
-__global__ void video_enc_bwd_rows_kernel(const float* __restrict__ df, const float* __restrict__ fv, const float* __restrict__ fs,
-                                          const float* __restrict__ vmask, int T, int D4, float* __restrict__ dv, float* __restrict__ dfs)
+// dv[b][t][:] = df * fs[b] * vmask[b][t] ;  dfs[b][:] = sum_t df[b][t][:] * fv[b][t][:]
+// grid (D/4 / 64, B), 64 x VE_PH threads: lane = feature group, threadIdx.y = time phase (t = ph, ph + VE_PH, ..); the phases'
+// partial sums meet in LDS in phase order (fixed order: deterministic).  One wave per (b, 64 feature groups) left the chip empty
+// for 0.12 ms at ActivityNet size.
+constexpr int VE_PH = 8;
+__global__ __launch_bounds__(64 * VE_PH)
+void video_enc_bwd_rows_kernel(const float* __restrict__ df, const float* __restrict__ fv, const float* __restrict__ fs,
+                               const float* __restrict__ vmask, int T, int D4, float* __restrict__ dv, float* __restrict__ dfs)
 {
-    const int d4 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (d4 >= D4) return;
-    const float4 s4 = ldg4(fs + ((size_t)b * D4 + d4) * 4);
+    __shared__ float4 part[VE_PH][64];
+    const int d4 = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, ph = threadIdx.y;
     float4 acc = f4zero();
-    for (int t = 0; t < T; ++t) {
-        const size_t o = (((size_t)b * T + t) * D4 + d4) * 4;
-        const float4 g = ldg4(df + o);
-        acc = f4add(acc, f4mul(g, ldg4(fv + o)));
-        stg4(dv + o, f4scale(f4mul(g, s4), vmask[(size_t)b * T + t]));
+    if (d4 < D4) {
+        const float4 s4 = ldg4(fs + ((size_t)b * D4 + d4) * 4);
+        for (int t = ph; t < T; t += VE_PH) {
+            const size_t o = (((size_t)b * T + t) * D4 + d4) * 4;
+            const float4 g = ldg4(df + o);
+            acc = f4add(acc, f4mul(g, ldg4(fv + o)));
+            stg4(dv + o, f4scale(f4mul(g, s4), vmask[(size_t)b * T + t]));
+        }
     }
-    stg4(dfs + ((size_t)b * D4 + d4) * 4, acc);
+    part[ph][threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0 && d4 < D4) {
+        for (int q = 1; q < VE_PH; ++q) acc = f4add(acc, part[q][threadIdx.x]);
+        stg4(dfs + ((size_t)b * D4 + d4) * 4, acc);
+    }
 }
 
 // dpe[t][:] = sum_b dv[b][t][:]                                                              grid (D/4 / 64, T)
@@ -65,7 +77,9 @@ extern "C" size_t smin_video_encoder_bwd_workspace_bytes(int B, int T, int Din, 
     return sizeof(float) * ((size_t)B * T * D + sp * ((size_t)D * Din + D) + 256);
 }
 
-// df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D]   (x receives no gradient: it is the input feature)
+// df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D]   (x receives no gradient: it is the input feature).
+// In two calls on the same ws: dW == NULL -> the inputs half only (dfs; the masked gradient stays in ws); df == NULL -> the weights half
+// (dW, dbias, dpe from ws as the inputs half left it).
 extern "C" int smin_video_encoder_bwd(void* stream, const float* df, const float* fv, const float* fs, const float* vmask, const float* x,
                                       int B, int T, int Din, int D, float* dW, float* dbias, float* dpe, float* dfs, void* ws, size_t ws_bytes)
 {
@@ -76,8 +90,12 @@ extern "C" int smin_video_encoder_bwd(void* stream, const float* df, const float
     const int R = B * T, D4 = D / 4, sp = tn_splits(R, D, Din);
     float* slab = dv + (size_t)R * D;
     float* bslab = slab + (size_t)sp * D * Din;
-    hipLaunchKernelGGL(video_enc_bwd_rows_kernel, dim3(cdiv(D4, 64), B), dim3(64), 0, st, df, fv, fs, vmask, T, D4, dv, dfs);
-    SMIN_LAUNCH_CHECK();
+    SMIN_REQUIRE(df != nullptr || dW != nullptr);
+    if (df) {                                                          // inputs half: dv (kept in ws for the weights half), dfs
+        hipLaunchKernelGGL(video_enc_bwd_rows_kernel, dim3(cdiv(D4, 64), B), dim3(64, VE_PH), 0, st, df, fv, fs, vmask, T, D4, dv, dfs);
+        SMIN_LAUNCH_CHECK();
+    }
+    if (!dW) return 0;
     hipLaunchKernelGGL(video_enc_bwd_pe_kernel, dim3(cdiv(D4, 64), T), dim3(64), 0, st, dv, B, T, D4, dpe);
     SMIN_LAUNCH_CHECK();
     int rc = launch_gemm_tn(st, PlainMat{dv, D}, PlainMat{x, Din}, slab, bslab, R, D, Din, sp); if (rc) return rc;
