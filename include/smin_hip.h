@@ -338,6 +338,10 @@ int smin_param_prep_bwd(void* stream, const float* const* params, int nl, int D,
 #define SMIN_BATCH_MAX 32
 int smin_transpose_batch(void* stream, const float* const* src, float* const* dst, const int32_t* rows, const int32_t* cols, int n);
 int smin_sum_lists(void* stream, const float* const* srcs, int n, size_t numel, float* out);
+/* out[c] = sum_r x[r][c]  (x [R][W], W % 4 == 0, W <= 1024): the bias gradient of a linear map whose weight gradient has no pass of its own
+ * to ride on (content stream: layer 0's constant).  Two fixed-order stages. */
+size_t smin_col_sum_workspace_bytes(int R, int W);
+int smin_col_sum(void* stream, const float* x, int R, int W, float* out, void* ws, size_t ws_bytes);
 
 /* ---- stand-alone fp32 MFMA GEMM  C[M][N] = A[M][K] * B[N][K]^T  (used by tests and bench.py's
  * roofline probe; same engine as every contraction above). */

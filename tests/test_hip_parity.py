@@ -908,6 +908,19 @@ def test_step_helpers_through_the_c_abi(dev):
     assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])
     assert (full[2].double() - dy.double().t() @ torch.cat([xa, xb], 1).double()).abs().max().item() < 1e-3
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0
+    # smin_col_sum: one block, many blocks, a width that does not divide the workgroup, no rows
+    for R_, W_ in [(5, 8), (300, 128), (70000, 128), (4099, 384), (1500, 1024), (0, 64)]:
+        xs_ = r(R_, W_) if R_ else torch.empty(0, W_, device=dev)
+        nb = lib.smin_col_sum_workspace_bytes(R_, W_)
+        wsc = torch.empty(nb + 64, dtype=torch.uint8, device=dev)
+        out = torch.full((W_,), 7.0, device=dev)
+        call("smin_col_sum", stream(), ptr(xs_), R_, W_, ptr(out), ptr(wsc), wsc.numel())
+        ref = xs_.double().sum(0)
+        assert (out.double() - ref).abs().max().item() <= 1e-6 * max(1.0, float(xs_.abs().sum(0).max()) if R_ else 1.0), (R_, W_)
+        out2 = torch.empty_like(out)
+        call("smin_col_sum", stream(), ptr(xs_), R_, W_, ptr(out2), ptr(wsc), wsc.numel())
+        assert torch.equal(out, out2)
+    assert lib.smin_col_sum(stream(), ptr(r(4, 6)), 4, 6, ptr(torch.empty(6, device=dev)), None, 0) < 0           # W % 4
     # video encoder and LSTM layer backward: inputs half, then weights half on the same workspace (the step runs the second on its weight stream)
     B, T, Din, D = 3, 50, 24, 64
     df, fv, fs, x = r(B * T, D), r(B * T, D), r(B, D), r(B * T, Din)

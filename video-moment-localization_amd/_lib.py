@@ -26,6 +26,8 @@ SIGNATURES = {
     "smin_param_prep_fwd": [_vp, _vp, _i, _i, _i] + [_vp] * 5,
     "smin_param_prep_bwd": [_vp, _vp, _i, _i, _i] + [_vp] * 9,
     "smin_sum_lists": [_vp, _vp, _i, _sz, _vp],
+    "smin_col_sum_workspace_bytes": [_i, _i],
+    "smin_col_sum": [_vp, _vp, _i, _i, _vp, _vp, _sz],
     "smin_proposal_map_fwd": [_vp, _vp, _vp] + [_i] * 6 + [_vp] * 3 + [_vp, _sz],
     "smin_proposal_map_bwd": [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp, _vp],
     "smin_clip_event_table": [_vp] + [_i] * 3 + [_vp] * 3,
@@ -77,7 +79,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
             "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz,
-            "smin_bilstm_layer_bwd_workspace_bytes": _sz, "smin_video_encoder_bwd_workspace_bytes": _sz, "smin_word_prep_bwd_workspace_bytes": _sz}
+            "smin_bilstm_layer_bwd_workspace_bytes": _sz, "smin_video_encoder_bwd_workspace_bytes": _sz, "smin_word_prep_bwd_workspace_bytes": _sz,
+            "smin_col_sum_workspace_bytes": _sz}
 
 _lib = None
 _ws = {}

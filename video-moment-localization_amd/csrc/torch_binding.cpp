@@ -1155,7 +1155,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
             SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
                                                tab.second.data_ptr()));
-            if (prep_kernel) at::sum_out(dconsts[0], dchat[0], at::IntArrayRef{0}); else dconsts[0] = dchat[0].sum(0);
+            if (!prep_kernel) dconsts[0] = at::empty({dl}, opt);
             keep.push_back(dg);
             const float* xs[1] = {fp(f)};
             wait_stream(wstr, curs);
@@ -1165,6 +1165,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 auto wsw = scratch(smin_linear_rows_bwd_workspace_bytes(i32(B * T), i32(nl * dl), D), dev);
                 SMIN_CK(smin_linear_rows_bwd(cur(), fp(dg), xs, 1, nullptr, i32(B * T), i32(nl * dl), D, nullptr, fpm(dWch_all), nullptr, wsw.p, wsw.n));
                 if (!prep_kernel) for (int64_t k = 0; k < nl; ++k) acc(dlp(k, L_CH_W), dWch_all.slice(0, k * dl, (k + 1) * dl));
+                // layer 0's constant: its gradient is the column sum of dchat_0 (the later layers' ride on their weight-gradient passes)
+                auto wsc = scratch(smin_col_sum_workspace_bytes(i32(N * C), dl), dev);
+                SMIN_CK(smin_col_sum(cur(), fp(dchat[0]), i32(N * C), dl, fpm(dconsts[0]), wsc.p, wsc.n));
             }
             weights_done = mark(wstr);
             // df = gradient through the proposal map (f_m, f_b) + gradient through the clip-window terms, the second accumulated by its

@@ -278,6 +278,57 @@ extern "C" int smin_sum_lists(void* stream, const float* const* srcs, int n, siz
 }
 
 namespace smin {
+// partial[blockIdx.x][:] = sum of rows [blockIdx.x * rpb, +rpb) of x [R][4*W4]; 256 threads = W4 float4 columns x (256 / W4) row groups,
+// four rows in flight per thread, the groups' sums meet in LDS in group order (fixed order: deterministic)
+__global__ __launch_bounds__(256)
+void col_sum_kernel(const float* __restrict__ x, int R, int W4, int rpb, float* __restrict__ partial)
+{
+    __shared__ float4 sh[256];
+    const int groups = 256 / W4, g = threadIdx.x / W4, c = threadIdx.x - g * W4;
+    const int r0 = blockIdx.x * rpb, r1 = min(R, r0 + rpb);
+    float4 s = f4zero();
+    if (g < groups) {
+        const float* p = x + (size_t)c * 4;
+        const size_t W = (size_t)W4 * 4;
+        int i = r0 + g;
+        for (; i + 3 * groups < r1; i += 4 * groups) {
+            const float4 a0 = ldg4(p + (size_t)i * W), a1 = ldg4(p + (size_t)(i + groups) * W), a2 = ldg4(p + (size_t)(i + 2 * groups) * W),
+                         a3 = ldg4(p + (size_t)(i + 3 * groups) * W);
+            s = f4add(f4add(f4add(f4add(s, a0), a1), a2), a3);
+        }
+        for (; i < r1; i += groups) s = f4add(s, ldg4(p + (size_t)i * W));
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0) {
+        for (int q = 1; q < groups; ++q) s = f4add(s, sh[q * W4 + c]);
+        stg4(partial + ((size_t)blockIdx.x * W4 + c) * 4, s);
+    }
+}
+static int col_sum_blocks(int R) { return R <= 0 ? 1 : cdiv(R, max(256, cdiv(R, 1024))); }
+}  // namespace smin
+
+extern "C" size_t smin_col_sum_workspace_bytes(int R, int W) { return sizeof(float) * (size_t)smin::col_sum_blocks(R) * (size_t)(W > 0 ? W : 0) + 64; }
+
+extern "C" int smin_col_sum(void* stream, const float* x, int R, int W, float* out, void* ws, size_t ws_bytes)
+{
+    using namespace smin;
+    SMIN_REQUIRE(W % 4 == 0 && W >= 4 && W <= 1024 && R >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) return (int)hipMemsetAsync(out, 0, sizeof(float) * (size_t)W, st);
+    SMIN_REQUIRE(ws_bytes >= smin_col_sum_workspace_bytes(R, W));
+    const int nb = col_sum_blocks(R), rpb = cdiv(R, nb);
+    float* partial = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), 0, st, x, R, W / 4, rpb, nb == 1 ? out : partial);
+    SMIN_LAUNCH_CHECK();
+    if (nb > 1) {
+        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(256), 0, st, partial, nb, W / 4, nb, out);
+        SMIN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+namespace smin {
 struct EpAccumTest {                // out += acc (same visit as the boundary unit's accumulate epilogue)
     float* out;
     __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
