@@ -592,6 +592,39 @@ def test_full_size_against_golden_bf16(dev, bf16_mode, name):
     print("bf16", name, "worst score error", worst, "worst gradient-norm deviation", dev_w)
 
 
+def test_bf16_operand_storage_changes_no_bit(dev, bf16_mode):
+    """Under plain bf16 contractions the pair product f_b[i]*f_b[j] is stored as bf16 (it only ever feeds contractions, whose loaders round
+    it to bf16 anyway): scores and every gradient equal the fp32-storage step bit for bit; and csrc's producer writes exactly torch's
+    round-to-nearest-even bf16 of the fp32 product."""
+    import ctypes
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    from vml_amd._lib import call, ptr, stream
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 128, 64, 4, 512, 128, 3, 500, 20, 256, 3
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    batch = O.synthetic_batch(B, T, L, Nq, Din, seed=5)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    res = []
+    for store in (True, False):
+        m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+        m.bf16_operand_storage = store
+        out = m(*H.model_inputs(b))
+        loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+        res.append(([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    for x, y in zip(res[0][0], res[1][0]):
+        assert torch.equal(x, y)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    g = torch.Generator().manual_seed(9)
+    Bn, Ln, Dn = 2, 7, 64
+    fb = torch.randn(Bn, Ln, Dn, generator=g).to(dev)
+    cells = torch.tensor([[bb, i, j, 1] for bb in range(Bn) for i in range(Ln) for j in range(i, Ln)], dtype=torch.int32, device=dev)
+    x1h = torch.empty(cells.shape[0], Dn, dtype=torch.bfloat16, device=dev)
+    call("smin_pair_product_bf16", stream(), ptr(fb), ptr(cells), cells.shape[0], Ln, Dn, ctypes.c_void_p(x1h.data_ptr()))
+    ref = (fb[cells[:, 0].long(), cells[:, 1].long()] * fb[cells[:, 0].long(), cells[:, 2].long()]).to(torch.bfloat16)
+    assert torch.equal(x1h.view(torch.int16), ref.view(torch.int16))
+
+
 def test_fused_loss_matches_torch_restatement(dev):
     """vml_amd.loss_fn on device (two fused kernels) against the torch restatement: value and the four score gradients."""
     from oracle import smin_oracle as O

@@ -93,6 +93,21 @@ struct CatMat {
         return ldg4(q + r.off + (c - sg * w));
     }
 };
+// [x1 | fcmean], both [rows][w], x1 stored as bf16 (the moment unit's left operand when the contractions round their operands to
+// bf16 anyway -- smin_set_gemm_mode(2): the stored values are exactly what the loader would have produced from fp32 storage)
+struct PairCatH {
+    const unsigned short* x1; const float* fcmean; int w;
+    struct Row { size_t off; };
+    struct Key {};
+    __device__ __forceinline__ Row row(int r) const { return Row{(size_t)r * w}; }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
+    __device__ __forceinline__ float4 at(const Row& r, int c) const {
+        if (c >= w) return ldg4(fcmean + r.off + (c - w));
+        const uint2 v = *reinterpret_cast<const uint2*>(x1 + r.off + c);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+};
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -68,6 +68,22 @@ __global__ void pair_product_kernel(const float* __restrict__ fb, const int* __r
     stg4(x1 + idx * 4, f4mul(ldg4(base + ((size_t)cl.i * D4 + d4) * 4), ldg4(base + ((size_t)cl.j * D4 + d4) * 4)));
 }
 
+// the same product rounded to bf16 (round to nearest even: the conversion the bf16 contraction modes apply to their operands)
+__global__ void pair_product_bf16_kernel(const float* __restrict__ fb, const int* __restrict__ cells, size_t N, int L, int D4, unsigned short* __restrict__ x1)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * D4) return;
+    const size_t n = idx / D4; const int d4 = (int)(idx % D4);
+    const Cell cl = load_cell(cells, n);
+    const float* base = fb + (size_t)cl.b * L * D4 * 4;
+    const float4 v = f4mul(ldg4(base + ((size_t)cl.i * D4 + d4) * 4), ldg4(base + ((size_t)cl.j * D4 + d4) * 4));
+    const __bf16 h[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    unsigned short u[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = __builtin_bit_cast(unsigned short, h[q]);
+    *reinterpret_cast<uint2*>(x1 + idx * 4) = make_uint2((unsigned)u[0] | ((unsigned)u[1] << 16), (unsigned)u[2] | ((unsigned)u[3] << 16));
+}
+
 static CatMat pair_cat(const float* x1, const float* fcmean, int D)
 {
     CatMat m;
@@ -80,16 +96,41 @@ static CatMat pair_cat(const float* x1, const float* fcmean, int D)
 
 using namespace smin;
 
-extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
-                                    int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu, const float* x1)
+static int moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
+                           int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu, const float* x1, const unsigned short* x1h)
 {
     (void)B;
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
     ProfScope prof(st, SMIN_PROF_MOMENT_FWD);
+    if (x1h && N > 0)
+        return launch_gemm_nt(st, PairCatH{x1h, fcmean, D}, PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
     if (!x1 || N == 0)
         return launch_gemm_nt(st, PairMeanMat{fb, fcmean, cells, L, D}, PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
     return launch_gemm_nt(st, pair_cat(x1, fcmean, D), PlainMat{Wcat, 2 * D}, EpMomentOut{bcat, cells, fm, mu}, N, D, 2 * D);
+}
+
+extern "C" int smin_moment_unit_fwd(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
+                                    int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu, const float* x1)
+{
+    return moment_unit_fwd(stream, fcmean, fm, fb, cells, N, B, L, D, Wcat, bcat, mu, x1, nullptr);
+}
+
+extern "C" int smin_moment_unit_fwd_x1h(void* stream, const float* fcmean, const float* fm, const float* fb, const int32_t* cells,
+                                        int N, int B, int L, int D, const float* Wcat, const float* bcat, float* mu, const uint16_t* x1h)
+{
+    SMIN_REQUIRE(x1h != nullptr || N == 0);
+    return moment_unit_fwd(stream, fcmean, fm, fb, cells, N, B, L, D, Wcat, bcat, mu, nullptr, x1h);
+}
+
+extern "C" int smin_pair_product_bf16(void* stream, const float* fb, const int32_t* cells, int N, int L, int D, uint16_t* x1h)
+{
+    SMIN_REQUIRE(D % 4 == 0);
+    if (N == 0) return 0;
+    const size_t tot = (size_t)N * (D / 4);
+    hipLaunchKernelGGL(pair_product_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fb, cells, (size_t)N, L, D / 4, x1h);
+    SMIN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int smin_pair_product(void* stream, const float* fb, const int32_t* cells, int N, int L, int D, float* x1)
@@ -102,10 +143,10 @@ extern "C" int smin_pair_product(void* stream, const float* fb, const int32_t* c
     return 0;
 }
 
-extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
-                                    const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
-                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
-                                    const float* dfcmean_acc, const float* x1)
+static int moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
+                           const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
+                           float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
+                           const float* dfcmean_acc, const float* x1, const unsigned short* x1h)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
@@ -135,6 +176,7 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
             {
                 ProfScope prof(st, SMIN_PROF_MOMENT_DW);
                 if (!all_valid) rc = launch_gemm_tn(st, MaskedRowsMat{dmu, D, cells}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
+                else if (x1h) rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairCatH{x1h, fcmean, D}, slab, bslab, N, D, 2 * D, sp);
                 else if (x1) rc = launch_gemm_tn(st, PlainMat{dmu, D}, pair_cat(x1, fcmean, D), slab, bslab, N, D, 2 * D, sp);
                 else rc = launch_gemm_tn(st, PlainMat{dmu, D}, PairMeanMat{fb, fcmean, cells, L, D}, slab, bslab, N, D, 2 * D, sp);
             }
@@ -150,4 +192,21 @@ extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float*
         SMIN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
+                                    const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
+                                    float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
+                                    const float* dfcmean_acc, const float* x1)
+{
+    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, x1, nullptr);
+}
+
+extern "C" int smin_moment_unit_bwd_x1h(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
+                                        const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
+                                        float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
+                                        const float* dfcmean_acc, const uint16_t* x1h)
+{
+    SMIN_REQUIRE(all_valid && (x1h != nullptr || N == 0));          // the stored product is a plain matrix: mask-driven cell lists only
+    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, nullptr, x1h);
 }

@@ -674,7 +674,7 @@ Tensor sum_list(const std::vector<Tensor>& ts)
 }
 
 struct SminCore : torch::autograd::Function<SminCore> {
-    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4 };
+    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4, F_BF16_OPERANDS = 8 };
     enum { N_FIXED = 13 };          // forward arguments ahead of the parameter list (tensors and scalars alike take one gradient slot)
 
     static variable_list forward(AutogradContext* ctx, Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask,
@@ -892,10 +892,20 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_C_W)), fp(lp(k, L_C_B)), fp(cumean), fp(ls.hbar), 1, n, D, dl, fpm(ls.cum)));
             }
             wait_stream(curs, side);
-            ls.x1 = at::empty_like(fm);                                            // f_b[i] * f_b[j], kept for the weight gradient
+            // f_b[i] * f_b[j], kept for the weight gradient.  With plain bf16 contractions (smin_set_gemm_mode(2)) it is stored as bf16: the
+            // loaders of both contractions that read it round it to bf16 anyway, so no bit of the step changes and the layer's largest saved
+            // tensor is half the bytes
+            const bool x1h = (flags & F_BF16_OPERANDS) && smin_get_gemm_mode() == 2;
+            ls.x1 = x1h ? at::empty({N, D}, opt.dtype(at::kBFloat16)) : at::empty_like(fm);
             Tensor mu = at::empty_like(fm);
-            SMIN_CK(smin_pair_product(cur(), fp(ls.bu), ip(cells), n, Li, D, fpm(ls.x1)));
-            SMIN_CK(smin_moment_unit_fwd(cur(), fp(ls.cum), fp(fm), fp(ls.bu), ip(cells), n, B, Li, D, fp(ls.Wcat), fp(bcat[k]), fpm(mu), fp(ls.x1)));
+            if (x1h) {
+                uint16_t* xh = reinterpret_cast<uint16_t*>(ls.x1.data_ptr());
+                SMIN_CK(smin_pair_product_bf16(cur(), fp(ls.bu), ip(cells), n, Li, D, xh));
+                SMIN_CK(smin_moment_unit_fwd_x1h(cur(), fp(ls.cum), fp(fm), fp(ls.bu), ip(cells), n, B, Li, D, fp(ls.Wcat), fp(bcat[k]), fpm(mu), xh));
+            } else {
+                SMIN_CK(smin_pair_product(cur(), fp(ls.bu), ip(cells), n, Li, D, fpm(ls.x1)));
+                SMIN_CK(smin_moment_unit_fwd(cur(), fp(ls.cum), fp(fm), fp(ls.bu), ip(cells), n, B, Li, D, fp(ls.Wcat), fp(bcat[k]), fpm(mu), fp(ls.x1)));
+            }
             fm = mu; cumean = ls.cum; fb = ls.bu;
         }
         // Localization (models.py:335-344)
@@ -992,8 +1002,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 StreamScope sc(wstr);
                 Tensor dWcat = prep_kernel ? dWcat_all[k] : at::empty_like(ls.Wcat), dbcat = prep_kernel ? dbcat_all[k] : at::empty({D}, opt);
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
-                SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
-                                             fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(ls.x1)));
+                if (ls.x1.scalar_type() == at::kBFloat16)
+                    SMIN_CK(smin_moment_unit_bwd_x1h(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
+                                                     fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, reinterpret_cast<const uint16_t*>(ls.x1.const_data_ptr())));
+                else
+                    SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
+                                                 fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(ls.x1)));
                 if (!prep_kernel) {
                     dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
                     dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
@@ -1002,7 +1016,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), fpm(dcum), fpm(dfb_mu),
-                                             nullptr, nullptr, ws.p, ws.n, 1, fp(dcum_next), fp(ls.x1)));
+                                             nullptr, nullptr, ws.p, ws.n, 1, fp(dcum_next), nullptr));          // (the pair product feeds the weight half only)
             }
             // boundary unit on the second stream
             Tensor dfb_k, dhbar_b;
@@ -1308,7 +1322,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
     const Tensor* loc = &prm[P_LAYER0 + nl * L_COUNT];
     if (cfg.size() >= 11 && cfg[10] != 0 && !video_features.requires_grad() && !query_features.requires_grad()) {      // the whole model as one node
         const int64_t flags = (overlap_boundary ? SminCore::F_OVERLAP_BOUNDARY : 0) | (overlap_prep ? SminCore::F_OVERLAP_PREP : 0) |
-                              ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0);
+                              ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0) | ((cfg.size() >= 13 && cfg[12] != 0) ? SminCore::F_BF16_OPERANDS : 0);
         auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
         Tensor psea = out[1];
         return std::make_tuple(out[0], psea[0], psea[1], psea[2]);

@@ -413,6 +413,7 @@ class SMIN(nn.Module):
 
     native_host = True             # run the in-model path as ONE torch-extension call (csrc/torch_binding.cpp); False: Python host
     async_weights = True           # ... whose weight-gradient contractions run on a low-priority stream of their own
+    bf16_operand_storage = True    # under set_gemm_mode("bf16"): tensors that only feed contractions are stored as bf16 (no bit of the step changes)
     fused_core = True              # ... with proposal map + SMI layers + localization as one autograd node (False: a node per module)
     content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
     overlap_boundary = True        # boundary unit on a second HIP stream beside the content stream
@@ -571,7 +572,7 @@ class SMIN(nn.Module):
             from . import _lib
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
                    int(self.overlap_boundary), int(self.overlap_prep and (self._streams_allowed("torch") or self._prep_is_library_code())), int(self.fused_core),
-                   int(self.async_weights)]
+                   int(self.async_weights), int(self.bf16_operand_storage)]
             return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
                                                   self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
