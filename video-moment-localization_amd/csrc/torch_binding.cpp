@@ -1311,7 +1311,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
                 " columns for ", query_features.size(1), " words (max_query_length ", cfg[6], ")");
     if (query_mask.size(1) < cfg[6]) query_mask = at::constant_pad_nd(query_mask, {0, cfg[6] - query_mask.size(1)}, 0);
     TORCH_CHECK(video_features.is_cuda(), "smin_forward runs on a HIP device only (there is no CPU fallback)");
-    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core)]");
+    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core, async_weights, bf16_operand_storage)]");
     const int64_t T = cfg[0], L = cfg[1], C = cfg[2], D = cfg[3], nl = cfg[5], maxq = cfg[6], H = cfg[7];
     const bool overlap_boundary = cfg[8] != 0, overlap_prep = cfg[9] != 0;
     TORCH_CHECK((int64_t)prm.size() == P_LAYER0 + nl * L_COUNT + 8, "smin_forward: expected ", P_LAYER0 + nl * L_COUNT + 8, " parameters, got ", prm.size());
