@@ -399,7 +399,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_with_adam": None if args.no_optimizer else ms,
             "ms_fwd_bwd": elapsed_fb / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "f32e": "f32 (emulated on the bf16 matrix cores: exact 3-way split, 6 products, fp32 accumulate)", "bf16x3": "f32 (split-bf16 products, fp32 accumulate)", "bf16": "bf16 (products, and storage of the pair product; fp32 accumulate, fp32 storage of everything an element-wise kernel reads)"}[args.gemm],
+            "dtype": {"f32": "f32", "f32e": "f32 (emulated on the bf16 matrix cores: exact 3-way split, 6 products, fp32 accumulate)", "bf16x3": "f32 (split-bf16 products, fp32 accumulate)", "bf16": "bf16 (products, and storage of the contraction-only tensors: pair product, attention outputs; fp32 accumulate, fp32 storage of everything an element-wise kernel reads)"}[args.gemm],
             "data": "synthetic" if args.feed == "resident" else "synthetic, fed from pinned host memory every step (BatchFeeder: async H2D + device-side targets)",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"

@@ -247,6 +247,11 @@ int smin_content_attn_fwd(void* stream, const float* chat, const int32_t* cells,
                           int N, int B, int L, int C, int dl, int Nq,
                           const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                           float* cc, float* ccmean);
+/* smin_content_attn_fwd with the rows stored as bf16 (cc_h [N*C][dl], round to nearest even) beside the fp32 clip mean */
+int smin_content_attn_fwd_cch(void* stream, const float* chat, const int32_t* cells, const int32_t* row_ptr,
+                              int N, int B, int L, int C, int dl, int Nq,
+                              const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                              uint16_t* cc_h, float* ccmean);
 size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl);
 /* dcc [N*C][dl] and/or dccmean [N][dl] (one may be NULL) -> dchat [N*C][dl], dMq, duq, dwhat, dshat. */
 int smin_content_attn_bwd(void* stream, const float* dcc, const float* dccmean, const float* chat,
@@ -264,6 +269,12 @@ int smin_linear_rows_fwd(void* stream, const float* const* xs, int nseg, const f
 size_t smin_linear_rows_bwd_workspace_bytes(int R, int O, int Ktot);
 int smin_linear_rows_bwd(void* stream, const float* dy, const float* const* xs, int nseg, const float* WT, int R, int O, int K,
                          float* const* dxs, float* dW, float* dbias, void* ws, size_t ws_bytes);
+/* smin_linear_rows_fwd / the weights half of smin_linear_rows_bwd for xs stored as bf16 (uint16_t bit patterns; contraction-only operands
+ * under smin_set_gemm_mode(2), where the results equal the fp32-storage calls bit for bit).  Forward: add_rows and add_cells required. */
+int smin_linear_rows_fwd_xh(void* stream, const uint16_t* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
+                            const float* add_cells, int C, int R, int O, int K, float* y);
+int smin_linear_rows_bwd_xh(void* stream, const float* dy, const uint16_t* const* xs, int nseg, int R, int O, int K,
+                            float* dW, float* dbias, void* ws, size_t ws_bytes);
 /* dx_s += dy W_s for every segment (WT as above): input gradients accumulated into tensors that already hold another consumer's gradient */
 int smin_linear_rows_dx_acc(void* stream, const float* dy, int nseg, const float* WT, int R, int O, int K, float* const* dxs);
 /* out[g][:] = sum_{c<C} x[g*C + c][:]   (x [groups*C][W]) */

@@ -63,9 +63,12 @@ SIGNATURES = {
     "smin_clip_window_means_fwd": [_vp] * 3 + [_i, _vp] + [_i] * 7 + [_vp, _vp, _sz],
     "smin_clip_window_means_bwd": [_vp] * 5 + [_i] * 7 + [_vp, _vp, _sz, _vp, _vp],
     "smin_content_attn_fwd": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
+    "smin_content_attn_fwd_cch": [_vp] * 4 + [_i] * 6 + [_vp] * 7,
     "smin_content_attn_bwd_workspace_bytes": [_i] * 4,
     "smin_content_attn_bwd": [_vp] * 6 + [_i] * 6 + [_vp] * 10 + [_vp, _sz],
     "smin_linear_rows_fwd": [_vp, _vp, _i] + [_vp] * 4 + [_i] * 4 + [_vp],
+    "smin_linear_rows_fwd_xh": [_vp, _vp, _i] + [_vp] * 4 + [_i] * 4 + [_vp],
+    "smin_linear_rows_bwd_xh": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz],
     "smin_linear_rows_bwd_workspace_bytes": [_i] * 3,
     "smin_linear_rows_bwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 3 + [_vp] * 3 + [_vp, _sz],
     "smin_linear_rows_dx_acc": [_vp, _vp, _i, _vp] + [_i] * 3 + [_vp],

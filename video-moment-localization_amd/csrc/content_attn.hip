@@ -292,7 +292,8 @@ static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + 
 
 // ROWS / MEAN: which outputs exist.  Compile-time: a runtime `if (pointer)` inside the unrolled output loop costs a branch
 // per 16-feature block and stops hipcc from scheduling across the blocks.
-template <int DL, int WS, bool ROWS, bool MEAN>
+// ROWS: 0 none, 1 fp32 rows, 2 rows stored as bf16 (round to nearest even; cchat then points to 16-bit elements)
+template <int DL, int WS, int ROWS, bool MEAN>
 __global__ __launch_bounds__(256, 2)
 void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
@@ -344,8 +345,16 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
                     fmac_nb_sum(o4[q], x, Ao[1], Ao[2], Ao[3]);
                 }
                 const int d = 16 * j + 4 * kg;
-                if (ROWS) {
+                if (ROWS == 1) {
                     if (gc.ok && d < dl) stg4(cchat + (size_t)gc.row * dl + d, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                }
+                if (ROWS == 2) {
+                    unsigned short u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) u[q] = __builtin_bit_cast(unsigned short, (__bf16)o4[q]);
+                    if (gc.ok && d < dl)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(cchat) + (size_t)gc.row * dl + d) =
+                            make_uint2((unsigned)u[0] | ((unsigned)u[1] << 16), (unsigned)u[2] | ((unsigned)u[3] << 16));
                 }
                 if (MEAN) {                                         // mean over the clips of the quad (padding lanes hold 0)
 #pragma unroll
@@ -633,21 +642,24 @@ int content_attn_bwd_range_cells(int N) { return range_cells(N, attn_num_cus(), 
 template <int DL, int WS>
 static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
-                 float* cc_rows, float* cc_mean, int dl, int Nq)
+                 float* cc_rows, float* cc_mean, int dl, int Nq, bool rows_bf16)
 {
     (void)B;
     const int cpr = range_cells(N, 2 * attn_num_cus(), 16);      // two 256-thread workgroups per CU (203 registers)
     const dim3 grid(cdiv(N, cpr));
     const size_t lds = fwd_lds_bytes<DL>();
     const float scale = 1.0f / sqrtf((float)dl);
-    if (cc_rows && cc_mean)
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, true, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+    if (rows_bf16)                                                // (rows + mean: the only bf16-rows combination a host asks for)
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 2, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+                           cc_rows, cc_mean, dl, Nq, N, cpr, scale);
+    else if (cc_rows && cc_mean)
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     else if (cc_rows)
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, true, false>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, false>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     else
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, false, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 0, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     SMIN_LAUNCH_CHECK();
     return 0;
@@ -672,7 +684,17 @@ int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells,
                             float* cc_rows, float* cc_mean, int dl, int Nq)
 {
     if (N <= 0) return 0;
-    SMIN_ATTN_DISPATCH(fwd_t, st, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq);
+    SMIN_ATTN_DISPATCH(fwd_t, st, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, false);
+}
+
+// the same with the rows stored as bf16 (cc_rows_h [N*C][dl] 16-bit) beside the fp32 clip mean
+int launch_content_attn_fwd_h(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
+                              const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                              unsigned short* cc_rows_h, float* cc_mean, int dl, int Nq)
+{
+    if (N <= 0) return 0;
+    float* cc_rows = reinterpret_cast<float*>(cc_rows_h);
+    SMIN_ATTN_DISPATCH(fwd_t, st, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_rows, cc_mean, dl, Nq, true);
 }
 
 // slabs: one per (range, sample) segment, indexed range + sample
@@ -743,6 +765,17 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
     SMIN_REQUIRE(cc || ccmean);
     ProfScope prof((hipStream_t)stream, SMIN_PROF_ATTN_FWD);
     return launch_content_attn_fwd((hipStream_t)stream, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc, ccmean, dl, Nq);
+}
+
+extern "C" int smin_content_attn_fwd_cch(void* stream, const float* chat, const int32_t* cells, const int32_t* row_ptr,
+                                         int N, int B, int L, int C, int dl, int Nq,
+                                         const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
+                                         uint16_t* cc_h, float* ccmean)
+{
+    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    if (N == 0) return 0;
+    SMIN_REQUIRE(cc_h && ccmean);
+    return launch_content_attn_fwd_h((hipStream_t)stream, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_h, ccmean, dl, Nq);
 }
 
 extern "C" size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl)

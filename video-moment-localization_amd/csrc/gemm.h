@@ -93,6 +93,10 @@ struct CatMat {
         return ldg4(q + r.off + (c - sg * w));
     }
 };
+__device__ __forceinline__ float4 ldg4_bf16(const unsigned short* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
 // [x1 | fcmean], both [rows][w], x1 stored as bf16 (the moment unit's left operand when the contractions round their operands to
 // bf16 anyway -- smin_set_gemm_mode(2): the stored values are exactly what the loader would have produced from fp32 storage)
 struct PairCatH {
@@ -104,8 +108,30 @@ struct PairCatH {
     __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
     __device__ __forceinline__ float4 at(const Row& r, int c) const {
         if (c >= w) return ldg4(fcmean + r.off + (c - w));
-        const uint2 v = *reinterpret_cast<const uint2*>(x1 + r.off + c);
-        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        return ldg4_bf16(x1 + r.off + c);
+    }
+};
+// bf16-stored operands of the same shapes as PlainMat / CatMat (contraction-only tensors under smin_set_gemm_mode(2), see PairCatH)
+struct PlainMatH {
+    const unsigned short* p; int ld;
+    struct Row { const unsigned short* p; };
+    struct Key {};
+    __device__ __forceinline__ Row row(int r) const { return Row{p + (size_t)r * ld}; }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
+    __device__ __forceinline__ float4 at(const Row& r, int c) const { return ldg4_bf16(r.p + c); }
+};
+struct CatMatH {
+    const unsigned short* p[4]; int w;
+    struct Row { size_t off; };
+    struct Key {};
+    __device__ __forceinline__ Row row(int r) const { return Row{(size_t)r * w}; }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
+    __device__ __forceinline__ float4 at(const Row& r, int c) const {
+        const int sg = (c >= w) + (c >= 2 * w) + (c >= 3 * w);
+        const unsigned short* q = sg == 0 ? p[0] : sg == 1 ? p[1] : sg == 2 ? p[2] : p[3];
+        return ldg4_bf16(q + r.off + (c - sg * w));
     }
 };
 // ------------------------------------------------------------------ helpers

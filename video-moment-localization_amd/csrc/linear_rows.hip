@@ -143,6 +143,52 @@ extern "C" int smin_linear_rows_bwd(void* stream, const float* dy, const float* 
     return 0;
 }
 
+// The two calls above that read xs, for xs stored as bf16 (contraction-only operands under smin_set_gemm_mode(2): bit-identical results,
+// half the operand bytes).  Forward: the combination the content stream uses for chat_k (rows and cells present, bias optional).
+// Backward: the weights half only (input gradients never read xs: smin_linear_rows_bwd / _dx_acc with xs == NULL serve them).
+static CatMatH cat_of_h(const uint16_t* const* xs, int nseg, int K)
+{
+    CatMatH m;
+    for (int k = 0; k < 4; ++k) m.p[k] = xs[k < nseg ? k : 0];
+    m.w = K;
+    return m;
+}
+
+extern "C" int smin_linear_rows_fwd_xh(void* stream, const uint16_t* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
+                                       const float* add_cells, int C, int R, int O, int K, float* y)
+{
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1 && nseg >= 1 && nseg <= 4 && add_rows != nullptr && add_cells != nullptr);
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    auto run = [&](auto ep) {
+        if (nseg == 1) return launch_gemm_nt(st, PlainMatH{xs[0], K}, PlainMat{W, K}, ep, R, O, K);
+        return launch_gemm_nt(st, cat_of_h(xs, nseg, K), PlainMat{W, nseg * K}, ep, R, O, nseg * K);
+    };
+    return bias ? run(EpLinearRows<true, true, true>{bias, add_rows, add_cells, C, y}) : run(EpLinearRows<false, true, true>{bias, add_rows, add_cells, C, y});
+}
+
+extern "C" int smin_linear_rows_bwd_xh(void* stream, const float* dy, const uint16_t* const* xs, int nseg, int R, int O, int K,
+                                       float* dW, float* dbias, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && nseg >= 1 && nseg <= 4 && dW != nullptr);
+    const int Kt = nseg * K;
+    if (R == 0) {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * Kt, st);
+        if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)O, st);
+        return 0;
+    }
+    SMIN_REQUIRE(ws_bytes >= smin_linear_rows_bwd_workspace_bytes(R, O, Kt));
+    const int sp = tn_splits(R, O, Kt);
+    float* slab = reinterpret_cast<float*>(ws);
+    float* bslab = slab + (size_t)sp * O * Kt;
+    int rc;
+    if (nseg == 1) rc = launch_gemm_tn(st, PlainMat{dy, O}, PlainMatH{xs[0], K}, slab, bslab, R, O, Kt, sp);
+    else rc = launch_gemm_tn(st, PlainMat{dy, O}, cat_of_h(xs, nseg, K), slab, bslab, R, O, Kt, sp);
+    if (rc) return rc;
+    return launch_reduce_slabs2(st, slab, dW, O * Kt, bslab, dbias, O, sp);
+}
+
 // dx_s += dy W_s for every segment: the input gradients of smin_linear_rows_bwd accumulated into tensors that already hold the
 // gradient of an earlier consumer (a separate full-size add per step otherwise)
 extern "C" int smin_linear_rows_dx_acc(void* stream, const float* dy, int nseg, const float* WT, int R, int O, int K, float* const* dxs)

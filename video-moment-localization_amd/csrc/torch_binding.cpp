@@ -43,6 +43,7 @@ using HStream = c10::hip::HIPStream;
 // ---------------------------------------------------------------- small helpers
 inline const float* fp(const Tensor& t) { return t.defined() ? t.const_data_ptr<float>() : nullptr; }
 inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline const uint16_t* hp16(const Tensor& t) { return reinterpret_cast<const uint16_t*>(t.const_data_ptr()); }     // bf16 tensors as bit patterns
 inline const int32_t* ip(const Tensor& t) { return t.const_data_ptr<int32_t>(); }
 inline void* cur() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
 inline Tensor cont(const Tensor& t) { return t.defined() ? t.contiguous() : t; }
@@ -840,6 +841,10 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
 
         Tensor cumean = fm, Hs;                                                    // mean_c f_c of the proposal map is f_m
+        // Tensors that only ever feed contractions (the pair product, the attention outputs cc_k) are stored as bf16 when the contractions
+        // round their operands to bf16 anyway (smin_set_gemm_mode(2)): no bit of the step changes, half the bytes
+        const bool bf16_operands = (flags & F_BF16_OPERANDS) && smin_get_gemm_mode() == 2;
+        const bool cc_bf16 = bf16_operands && dl % 8 == 0;
         for (int64_t k = 0; k < nl; ++k) {
             LayerState& ls = st.layer[k];
             const bool lastl = k == nl - 1;
@@ -875,27 +880,35 @@ struct SminCore : torch::autograd::Function<SminCore> {
                     SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_CH_W)), nullptr, nullptr, nullptr, 1, n, dl, D, fpm(hp)));
                 }
                 const int nseg = i32(std::min<int64_t>(4, k - lo));
-                const float* xs[4];
-                for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
                 Tensor y = at::empty({N * C, dl}, opt);
-                SMIN_CK(smin_linear_rows_fwd(cur(), xs, nseg, fp(ls.Pcat[part]), lo == 0 ? fp(ls.consts) : nullptr, fp(chat), fp(hp), Ci, i32(N * C), dl, dl, fpm(y)));
+                if (cc_bf16) {
+                    const uint16_t* xh[4];
+                    for (int sgm = 0; sgm < nseg; ++sgm) xh[sgm] = hp16(st.layer[lo + sgm].cc);
+                    SMIN_CK(smin_linear_rows_fwd_xh(cur(), xh, nseg, fp(ls.Pcat[part]), lo == 0 ? fp(ls.consts) : nullptr, fp(chat), fp(hp), Ci, i32(N * C), dl, dl, fpm(y)));
+                } else {
+                    const float* xs[4];
+                    for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
+                    SMIN_CK(smin_linear_rows_fwd(cur(), xs, nseg, fp(ls.Pcat[part]), lo == 0 ? fp(ls.consts) : nullptr, fp(chat), fp(hp), Ci, i32(N * C), dl, dl, fpm(y)));
+                }
                 chat = y;
             }
             ls.chat = chat;
             if (k == 0 && prep != curs) await(curs, words_ready);
-            ls.cc = at::empty({lastl ? 0 : N * C, dl}, opt); ls.ccmean = at::empty({N, dl}, opt);
-            SMIN_CK(smin_content_attn_fwd(cur(), fp(chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]), fp(st.shat[k]), fp(qmf),
-                                          lastl ? nullptr : fpm(ls.cc), fpm(ls.ccmean)));
+            ls.cc = at::empty({lastl ? 0 : N * C, dl}, cc_bf16 ? opt.dtype(at::kBFloat16) : opt); ls.ccmean = at::empty({N, dl}, opt);
+            if (cc_bf16 && !lastl)
+                SMIN_CK(smin_content_attn_fwd_cch(cur(), fp(chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]), fp(st.shat[k]),
+                                                  fp(qmf), reinterpret_cast<uint16_t*>(ls.cc.data_ptr()), fpm(ls.ccmean)));
+            else
+                SMIN_CK(smin_content_attn_fwd(cur(), fp(chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]), fp(st.shat[k]), fp(qmf),
+                                              lastl ? nullptr : fpm(ls.cc), fpm(ls.ccmean)));
             ls.cum = at::empty({N, D}, opt);
             {
                 const float* xs[1] = {fp(ls.ccmean)};
                 SMIN_CK(smin_linear_rows_fwd(cur(), xs, 1, fp(lp(k, L_C_W)), fp(lp(k, L_C_B)), fp(cumean), fp(ls.hbar), 1, n, D, dl, fpm(ls.cum)));
             }
             wait_stream(curs, side);
-            // f_b[i] * f_b[j], kept for the weight gradient.  With plain bf16 contractions (smin_set_gemm_mode(2)) it is stored as bf16: the
-            // loaders of both contractions that read it round it to bf16 anyway, so no bit of the step changes and the layer's largest saved
-            // tensor is half the bytes
-            const bool x1h = (flags & F_BF16_OPERANDS) && smin_get_gemm_mode() == 2;
+            // f_b[i] * f_b[j], kept for the weight gradient (bf16 under bf16_operands: the layer's largest saved tensor)
+            const bool x1h = bf16_operands;
             ls.x1 = x1h ? at::empty({N, D}, opt.dtype(at::kBFloat16)) : at::empty_like(fm);
             Tensor mu = at::empty_like(fm);
             if (x1h) {
@@ -1062,7 +1075,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 const bool have = dcc[lo].defined();
                 for (int sgm = 0; sgm < nseg; ++sgm) {
                     TORCH_CHECK(dcc[lo + sgm].defined() == have, "content stream: inconsistent gradient state of the attention outputs");
-                    xs[sgm] = fp(st.layer[lo + sgm].cc);
+                    xs[sgm] = nullptr;                                             // (the input gradients never read the operands)
                     if (!have) dcc[lo + sgm] = at::empty({N * C, dl}, opt);
                     dxs[sgm] = fpm(dcc[lo + sgm]);
                 }
@@ -1096,12 +1109,18 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 }
                 for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
                     const int nseg = i32(std::min<int64_t>(4, k - lo));
-                    const float* xs[4];
-                    for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
                     Tensor dP = at::empty_like(ls.Pcat[part]);
                     if (lo == 0 && !prep_kernel) dconsts[k] = at::empty({dl}, opt);
                     auto ws = scratch(smin_linear_rows_bwd_workspace_bytes(i32(N * C), dl, nseg * dl), dev);
-                    SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, nullptr, i32(N * C), dl, dl, nullptr, fpm(dP), lo == 0 ? fpm(dconsts[k]) : nullptr, ws.p, ws.n));
+                    if (st.layer[lo].cc.scalar_type() == at::kBFloat16) {
+                        const uint16_t* xh[4];
+                        for (int sgm = 0; sgm < nseg; ++sgm) xh[sgm] = hp16(st.layer[lo + sgm].cc);
+                        SMIN_CK(smin_linear_rows_bwd_xh(cur(), fp(dchat[k]), xh, nseg, i32(N * C), dl, dl, fpm(dP), lo == 0 ? fpm(dconsts[k]) : nullptr, ws.p, ws.n));
+                    } else {
+                        const float* xs[4];
+                        for (int sgm = 0; sgm < nseg; ++sgm) xs[sgm] = fp(st.layer[lo + sgm].cc);
+                        SMIN_CK(smin_linear_rows_bwd(cur(), fp(dchat[k]), xs, nseg, nullptr, i32(N * C), dl, dl, nullptr, fpm(dP), lo == 0 ? fpm(dconsts[k]) : nullptr, ws.p, ws.n));
+                    }
                     dPcat[k].push_back(dP);
                 }
                 if (k > 0) {
