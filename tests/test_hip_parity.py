@@ -625,6 +625,21 @@ def test_bf16_operand_storage_changes_no_bit(dev, bf16_mode):
     assert torch.equal(x1h.view(torch.int16), ref.view(torch.int16))
 
 
+def test_bf16_mode_with_no_valid_cell(dev, bf16_mode):
+    """bf16-stored operands and an empty cell list (every length mask false): zero scores, finite gradients, no rejected argument."""
+    from oracle import smin_oracle as O
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 64, 16, 4, 128, 32, 3, 40, 9, 64, 3
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+    b = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=4).items()}
+    b["length_mask"][:] = False
+    b["moment_mask"][:] = False
+    out = m(*H.model_inputs(b))
+    assert all(float(o.detach().abs().max()) == 0.0 for o in out)
+    sum(o.sum() for o in out).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_fused_loss_matches_torch_restatement(dev):
     """vml_amd.loss_fn on device (two fused kernels) against the torch restatement: value and the four score gradients."""
     from oracle import smin_oracle as O

@@ -157,8 +157,9 @@ static CatMatH cat_of_h(const uint16_t* const* xs, int nseg, int K)
 extern "C" int smin_linear_rows_fwd_xh(void* stream, const uint16_t* const* xs, int nseg, const float* W, const float* bias, const float* add_rows,
                                        const float* add_cells, int C, int R, int O, int K, float* y)
 {
-    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1 && nseg >= 1 && nseg <= 4 && add_rows != nullptr && add_cells != nullptr);
+    SMIN_REQUIRE(O % 4 == 0 && K % 4 == 0 && C >= 1 && nseg >= 1 && nseg <= 4);
     if (R == 0) return 0;
+    SMIN_REQUIRE(add_rows != nullptr && add_cells != nullptr);
     hipStream_t st = (hipStream_t)stream;
     auto run = [&](auto ep) {
         if (nseg == 1) return launch_gemm_nt(st, PlainMatH{xs[0], K}, PlainMat{W, K}, ep, R, O, K);
