@@ -373,19 +373,34 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
 }
 
 // ---- backward with the word-side reductions fused ---------------------------------------------------------------------
-// 512 threads = 8 waves, one workgroup per CU.  LDS (floats):
-//   sM [32][DL+4] | sW [32][DL+4] | sS [DL] | sU [32] | sQ [32] | tDa [128][DL+4] | tDs [128][36] | tP [128][36]
-// A round = 8 tiles (one per wave) = 32 cells = 128 rows:  tile phase (per wave, as the forward + gradients; dchat to HBM;
-// da, dS, P rows into the round tiles)  ->  barrier  ->  reduction phase: wave (kind, fq) accumulates the 32 x 32 block
-// [32 slots] x [features 32fq ..] of dMq = dS^T chat (kind 0; chat rows come back from L2) or dwhat = P^T da (kind 1) over
-// the 128 rows with 64 v_mfma_f32_32x32x2_f32, plus the column sums duq / dshat  ->  barrier.
+// 256 threads = 4 waves (one per SIMD), TWO workgroups per CU: the two run out of phase, so that one workgroup's matrix-dense
+// reduction phase fills the matrix pipe while the other sits in the dependent chains of its tile phase (round 2 ran one
+// 512-thread workgroup per CU whose eight waves were all in the same phase: 35 % matrix-pipe occupancy).  LDS (floats):
+//   sM [32][DL+4] | sW [32][DL+4] | sS [DL] | sU [32] | sQ [32] | X [64][DL+4] | tDs [64][LDP] | tP [64][LDP] | 32 slack
+// A round = 4 tiles (one per wave) = 16 cells = 64 rows:
+//   T   tile phase, per wave: forward recompute + gradients; dchat to HBM; the a rows are parked in X between their two uses
+//       (clip-attention scores, then dq) instead of being recomputed; X then takes the da rows; dS / P rows into tDs / tP
+//   R1  wave fq accumulates the 32 x 32 block [32 columns] x [features 32fq ..] of dwhat = P^T da (+ dshat = colsum da)
+//       over the 64 rows with 32 v_mfma_f32_32x32x2_f32
+//   W   every wave writes its chat rows (still in registers) over the da rows of X
+//   R0  the same for dMq = dS^T chat (+ duq = colsum dS): the chat rows come from LDS, not a second time from L2 / HBM
+// tDs / tP keep only the columns that can hold a word: the 16 slots of block 0, then the valid slots 16 + 4kg + r (r < WS - 4)
+// of block 1 as column 16 + kg (WS - 4) + r; columns past that read the next row (finite garbage) and their results are dropped.
 // Per (range, sample) segment the accumulators go to slab[range + sample]:  [dM 32 x dl | dW 32 x dl | dshat dl | du 32]
-// in slot order; content_attn_reduce_kernel sums a sample's slabs in range order (fixed order: deterministic).
-template <int DL>
-static size_t bwd_lds_bytes() { return sizeof(float) * (size_t)(64 * (DL + 4) + DL + 64 + 128 * (DL + 4) + 256 * LDP); }
+// in column order; content_attn_reduce_kernel sums a sample's slabs in range order (fixed order: deterministic).
+template <int WS> constexpr int bwd_ldp() { return WS <= 5 ? 20 : (WS == 6 ? 28 : 36); }
+template <int WS> constexpr int bwd_ncols() { return 16 + 4 * (WS - 4); }
+template <int DL, int WS>
+static size_t bwd_lds_bytes() { return sizeof(float) * (size_t)(64 * (DL + 4) + DL + 64 + 64 * (DL + 4) + 128 * bwd_ldp<WS>() + 32); }
+// word held by column c of the round tiles / slabs (nb1 = WS - 4 valid slots per lane group in block 1)
+__device__ __host__ __forceinline__ int col_word(int c, int nb1) {
+    if (c < 16) return 4 * (c & 3) + (c >> 2);
+    const int e = c - 16, d = nb1 > 0 ? nb1 : 1;
+    return 16 + 4 * (e % d) + e / d;
+}
 
 template <int DL, int WS, bool MEAN2, bool PERCELL>
-__global__ __launch_bounds__(512, 2)
+__global__ __launch_bounds__(256, 2)
 void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
                              const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
@@ -395,59 +410,54 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                              const float* __restrict__ dmean2, float mscale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    constexpr int LDM = DL + 4, KJ = DL / 16, LDA = DL + 4, DT = (DL + 31) / 32;
+    constexpr int LDM = DL + 4, KJ = DL / 16, LDA = DL + 4, DT = (DL + 31) / 32, LDP = bwd_ldp<WS>(), NB1 = WS - 4, NCOLS = bwd_ncols<WS>();
     float* sM = smem_dyn; float* sW = sM + 32 * LDM; float* sS = sW + 32 * LDM; float* sU = sS + DL; float* sQ = sU + 32;
-    float* tDa = sQ + 32; float* tDs = tDa + 128 * LDA; float* tP = tDs + 128 * LDP;
+    float* X = sQ + 32; float* tDs = X + 64 * LDA; float* tP = tDs + 64 * LDP;
     const int rg = blockIdx.x;
     const int n_lo = rg * cells_per_range;
     if (n_lo >= N) return;
     const int n_hi = min(N, n_lo + cells_per_range);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kg = lane >> 4, l15 = lane & 15;
-    const int kind = wave >> 2, fq = wave & 3, l31 = lane & 31, h = lane >> 5;
+    const int fq = wave, l31 = lane & 31, h = lane >> 5;
     const size_t slab_sz = (size_t)64 * dl + dl + 32;
+    if (threadIdx.x < 32) tP[64 * LDP + threadIdx.x] = 0.f;       // the slack the last row's dropped columns read
+    float* myX = X + (16 * wave + l15) * LDA;
 
     for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
         const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
         const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
         __syncthreads();
-        stage_slot_major<DL, 512>(sM, Mq, b, dl, Nq);
-        stage_slot_major<DL, 512>(sW, what, b, dl, Nq);
-        stage_vectors<DL, 512>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
+        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq);
+        stage_slot_major<DL, 256>(sW, what, b, dl, Nq);
+        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
         __syncthreads();
-        f32x16 racc;
+        f32x16 racc0, racc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        float csum = 0.f;
+        for (int r = 0; r < 16; ++r) { racc0[r] = 0.f; racc1[r] = 0.f; }
+        float cs0 = 0.f, cs1 = 0.f;
 
         // the rows of a round (chat, output gradients) are requested one round ahead, before the previous round's reduction
-        // phase, so that their HBM latency hides behind it
+        // phases, so that their HBM latency hides behind them
         float4 raw[KJ], gq[KJ], gm[KJ];
         RowGeom g = row_geom16(cells, n + 4 * wave, seg_end, C, lane);
         fetch_rows16<DL>(raw, chat, g.row, dl, kg);
         fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
         if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
 
-        for (int c0 = n; c0 < seg_end; c0 += 32) {                // rounds
+        for (int c0 = n; c0 < seg_end; c0 += 16) {                // rounds
+            float ch[KJ][4];
             {
-                float ch[KJ][4], P[8], Ao[4];
-                float gv[KJ][4];                                    // effective output-gradient rows (both consumers summed, masked)
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    const bool dok = g.ok && 16 * j + 4 * kg < dl;
-                    const float gs = dok ? gscale : 0.f, ms = dok ? mscale : 0.f;
-                    gv[j][0] = gq[j].x * gs; gv[j][1] = gq[j].y * gs; gv[j][2] = gq[j].z * gs; gv[j][3] = gq[j].w * gs;
-                    if (MEAN2) {
-                        gv[j][0] = fmaf(gm[j].x, ms, gv[j][0]); gv[j][1] = fmaf(gm[j].y, ms, gv[j][1]);
-                        gv[j][2] = fmaf(gm[j].z, ms, gv[j][2]); gv[j][3] = fmaf(gm[j].w, ms, gv[j][3]);
-                    }
-                }
+                float P[8], Ao[4];
                 mask_rows16<DL>(ch, raw, g.ok, dl, kg);
                 __builtin_amdgcn_sched_barrier(0);                  // the prefetched registers die here
                 scores_softmax16<DL, WS>(P, ch, sM, sU, sQ, Nq, scale, lane);
                 __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                    // the previous round's R0 is done with X / tDs (first writes below)
                 clip_attention16<DL>(Ao, ch, sS, g, scale, lane, [&](int j) {
                     f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
-                    return words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
+                    const f32x4v acc = words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
+                    stg4(myX + 16 * j + 4 * kg, make_float4(acc[0], acc[1], acc[2], acc[3]));      // parked for the dq pass
+                    return acc;
                 });
 
                 // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
@@ -456,9 +466,17 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
+                    // effective output-gradient rows (both consumers summed, masked); the rows were requested a phase ago
+                    const bool dok = g.ok && 16 * j + 4 * kg < dl;
+                    const float gs = dok ? gscale : 0.f, ms = dok ? mscale : 0.f;
+                    float gvj[4] = {gq[j].x * gs, gq[j].y * gs, gq[j].z * gs, gq[j].w * gs};
+                    if (MEAN2) {
+                        gvj[0] = fmaf(gm[j].x, ms, gvj[0]); gvj[1] = fmaf(gm[j].y, ms, gvj[1]);
+                        gvj[2] = fmaf(gm[j].z, ms, gvj[2]); gvj[3] = fmaf(gm[j].w, ms, gvj[3]);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float x = ch[j][q], y = gv[j][q];
+                        const float x = ch[j][q], y = gvj[q];
                         dAo[0] = fmaf(y, x, dAo[0]);
                         fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
                         dch[j][q] = Ao[0] * y;
@@ -480,28 +498,27 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     sym[2] = (dZ[2] + nb<2>(dZ[2])) * scale;
                     sym[3] = (dZ[3] + nb<3>(dZ[3])) * scale;
                 }
-                // per 16-feature block: a (MFMA) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
-                //                       -> da into the round tile and straight into  dP^T[slot][n] += sum_d what[slot][d] da^T[d][n]  (MFMA)
+                // per 16-feature block: a (back from X) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
+                //                       -> da into X and straight into  dP^T[slot][n] += sum_d what[slot][d] da^T[d][n]  (MFMA)
                 f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f};
-                float* myDa = tDa + (16 * wave + l15) * LDA;
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
-                    f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4v acc = words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
-                    const float4 sh = ldg4(sS + 16 * j + 4 * kg);
+                    const int d = 16 * j + 4 * kg;
+                    const float4 a4 = ldg4(myX + d);
+                    const float av4[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float4 sh = ldg4(sS + d);
                     const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
                     float da4[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float tq = acc[q] + shv[q];
+                        const float tq = av4[q] + shv[q];
                         const float qv = ch[j][q] * tq;
                         float dq = sym[0] * qv;
                         fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
                         dch[j][q] = fmaf(dq, tq, dch[j][q]);
                         da4[q] = dq * ch[j][q];                     // 0 on padding lanes and past dl (ch is 0 there)
                     }
-                    const int d = 16 * j + 4 * kg;
-                    stg4(myDa + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
+                    stg4(myX + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
                     const float4 w0 = ldg4(sW + l15 * LDM + d);
                     dP0 = mfma16(w0.x, da4[0], dP0); dP0 = mfma16(w0.y, da4[1], dP0); dP0 = mfma16(w0.z, da4[2], dP0); dP0 = mfma16(w0.w, da4[3], dP0);
                     if (WS > 4) {
@@ -522,10 +539,16 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 {
                     float* myDs = tDs + (16 * wave + l15) * LDP;
                     float* myP = tP + (16 * wave + l15) * LDP;
-#pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        stg4(myDs + 16 * b2 + 4 * kg, make_float4(dS[4 * b2], dS[4 * b2 + 1], dS[4 * b2 + 2], dS[4 * b2 + 3]));
-                        stg4(myP + 16 * b2 + 4 * kg, g.ok ? make_float4(P[4 * b2], P[4 * b2 + 1], P[4 * b2 + 2], P[4 * b2 + 3]) : f4zero());
+                    stg4(myDs + 4 * kg, make_float4(dS[0], dS[1], dS[2], dS[3]));
+                    stg4(myP + 4 * kg, g.ok ? make_float4(P[0], P[1], P[2], P[3]) : f4zero());
+                    if (NB1 == 1) { myDs[16 + kg] = dS[4]; myP[16 + kg] = g.ok ? P[4] : 0.f; }
+                    if (NB1 == 2) {
+                        *reinterpret_cast<float2*>(myDs + 16 + 2 * kg) = make_float2(dS[4], dS[5]);
+                        *reinterpret_cast<float2*>(myP + 16 + 2 * kg) = g.ok ? make_float2(P[4], P[5]) : make_float2(0.f, 0.f);
+                    }
+                    if (NB1 == 4) {
+                        stg4(myDs + 16 + 4 * kg, make_float4(dS[4], dS[5], dS[6], dS[7]));
+                        stg4(myP + 16 + 4 * kg, g.ok ? make_float4(P[4], P[5], P[6], P[7]) : f4zero());
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -539,48 +562,37 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // next round's rows (past the segment: clamped to its last row, never used)
-            g = row_geom16(cells, c0 + 32 + 4 * wave, seg_end, C, lane);
+            // next round's chat rows (past the segment: clamped to its last row, never used)
+            g = row_geom16(cells, c0 + 16 + 4 * wave, seg_end, C, lane);
             fetch_rows16<DL>(raw, chat, g.row, dl, kg);
-            fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
-            if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+            const int feat = 32 * fq + l31;
+            const float* Bt = X + h * LDA + min(feat, DL - 1);
             __syncthreads();                                        // the round's da / dS / P rows are in LDS
-            if (fq < DT) {
-                const int feat = 32 * fq + l31;
-                const bool fok = feat < dl;
-                const float* At = (kind ? tP : tDs) + h * LDP + l31;
-                if (kind) {
-                    const float* Bt = tDa + h * LDA + min(feat, DL - 1);
+            if (fq < DT) {                                          // R1: dwhat += P^T da, dshat += colsum da
+                const float* At = tP + h * LDP + l31;
 #pragma unroll 8
-                    for (int s2 = 0; s2 < 64; ++s2) {
-                        const float bv = Bt[2 * s2 * LDA];
-                        racc = mfma32(At[2 * s2 * LDP], bv, racc);
-                        csum += bv;                                 // dshat[feat]
-                    }
-                } else {
-                    // chat rows of the round back from L2 (this workgroup has just read them), 16 rows in flight
-                    const float* cbase = chat + min(feat, dl - 1);
-#pragma unroll
-                    for (int s0 = 0; s0 < 64; s0 += 8) {
-                        float bv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int t = 2 * (s0 + u) + h, cell = c0 + (t >> 2), c = t & 3;
-                            const bool ok = cell < seg_end && c < C;
-                            const size_t row = ok ? (size_t)cell * C + c : (size_t)c0 * C;
-                            const float x = cbase[row * dl];
-                            bv[u] = (ok && fok) ? x : 0.f;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const float av = At[2 * (s0 + u) * LDP];
-                            racc = mfma32(av, bv[u], racc);
-                            csum += av;                             // duq[slot]
-                        }
-                    }
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    const float bv = Bt[2 * s2 * LDA];
+                    racc1 = mfma32(At[2 * s2 * LDP], bv, racc1);
+                    cs1 += bv;
                 }
             }
-            __syncthreads();                                        // tiles may be overwritten by the next round
+            __syncthreads();                                        // every wave is done with the da rows
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) stg4(myX + 16 * j + 4 * kg, make_float4(ch[j][0], ch[j][1], ch[j][2], ch[j][3]));      // W
+            // next round's gradient rows: requested now that the chat registers are free, consumed a third into the tile phase
+            fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
+            if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+            __syncthreads();
+            if (fq < DT) {                                          // R0: dMq += dS^T chat, duq += colsum dS
+                const float* At = tDs + h * LDP + l31;
+#pragma unroll 8
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    const float av = At[2 * s2 * LDP];
+                    racc0 = mfma32(av, Bt[2 * s2 * LDA], racc0);
+                    cs0 += av;
+                }
+            }
         }
         // the segment's partial result
         float* sl = slab + (size_t)(rg + b) * slab_sz;
@@ -588,12 +600,18 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
             const int feat = 32 * fq + l31;
             if (feat < dl) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sl[(size_t)(kind * 32 + wmap(r, h)) * dl + feat] = racc[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int col = wmap(r, h);
+                    if (col < NCOLS) {
+                        sl[(size_t)col * dl + feat] = racc0[r];
+                        sl[(size_t)(32 + col) * dl + feat] = racc1[r];
+                    }
+                }
             }
-            const float cs = csum + __shfl_xor(csum, 32);
+            const float c1 = cs1 + __shfl_xor(cs1, 32), c0s = cs0 + __shfl_xor(cs0, 32);
             if (h == 0) {
-                if (kind) { if (feat < dl) sl[(size_t)64 * dl + feat] = cs; }
-                else if (fq == 0) sl[(size_t)64 * dl + dl + l31] = cs;
+                if (feat < dl) sl[(size_t)64 * dl + feat] = c1;
+                if (fq == 0) sl[(size_t)64 * dl + dl + l31] = c0s;
             }
         }
         n = seg_end;
@@ -602,22 +620,27 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
 
 // dMq / dwhat / dshat / duq of sample b = sum of its segments' slabs, in range order
 __global__ void content_attn_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ row_ptr, int L, int dl, int Nq, int cells_per_range,
-                                           float* __restrict__ dMq, float* __restrict__ dwhat, float* __restrict__ dshat, float* __restrict__ duq)
+                                           int nb1, float* __restrict__ dMq, float* __restrict__ dwhat, float* __restrict__ dshat, float* __restrict__ duq)
 {
     const int b = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slab_sz = 2 * 32 * dl + dl + 32;
+    const int slab_sz = 2 * 32 * dl + dl + 32, ncols = 16 + 4 * nb1;
     if (x >= slab_sz) return;
+    // which output element this is (columns that hold no word are never summed: their slab entries are not written)
+    float* out = nullptr;
+    if (x < 64 * dl) {
+        const int y = x < 32 * dl ? x : x - 32 * dl, c = y / dl, d = y % dl, w = col_word(c, nb1);
+        if (c < ncols && w < Nq) out = (x < 32 * dl ? dMq : dwhat) + ((size_t)b * Nq + w) * dl + d;
+    } else if (x < 64 * dl + dl) out = dshat + (size_t)b * dl + (x - 64 * dl);
+    else { const int c = x - 64 * dl - dl, w = col_word(c, nb1); if (c < ncols && w < Nq) out = duq + (size_t)b * Nq + w; }
+    if (!out) return;
     const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
     float s = 0.f;
     if (s1 > s0) {
         const int g_lo = s0 / cells_per_range, g_hi = (s1 - 1) / cells_per_range;
         for (int g = g_lo; g <= g_hi; ++g) s += slab[(size_t)(g + b) * slab_sz + x];
     }
-    if (x < 32 * dl) { const int w = slot_word(x / dl), d = x % dl; if (w < Nq) dMq[((size_t)b * Nq + w) * dl + d] = s; }
-    else if (x < 64 * dl) { const int y = x - 32 * dl, w = slot_word(y / dl), d = y % dl; if (w < Nq) dwhat[((size_t)b * Nq + w) * dl + d] = s; }
-    else if (x < 64 * dl + dl) dshat[(size_t)b * dl + (x - 64 * dl)] = s;
-    else { const int w = slot_word(x - 64 * dl - dl); if (w < Nq) duq[(size_t)b * Nq + w] = s; }
+    *out = s;
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
@@ -637,7 +660,7 @@ static int range_cells(int N, int slots, int min_cells)
     int c = cdiv(cdiv(N, slots), 4) * 4;
     return c < min_cells ? min_cells : c;
 }
-int content_attn_bwd_range_cells(int N) { return range_cells(N, attn_num_cus(), 32); }
+int content_attn_bwd_range_cells(int N) { return range_cells(N, 2 * attn_num_cus(), 16); }      // two 256-thread workgroups per CU, whole rounds
 
 template <int DL, int WS>
 static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
@@ -714,15 +737,16 @@ static int bwd_v(hipStream_t st, const float* chat, const float* dcchat, const i
     static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)bwd_lds_bytes<DL>());
+                                           (int)(bwd_lds_bytes<DL, WS>()));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), dim3(cdiv(N, cpr)), dim3(512), bwd_lds_bytes<DL>(), st, chat, dcchat, cells, row_ptr, L, C,
+    const size_t lds = bwd_lds_bytes<DL, WS>();
+    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), dim3(cdiv(N, cpr)), dim3(256), lds, st, chat, dcchat, cells, row_ptr, L, C,
                        Mq, uq, what, shat, qmask, dchat, ws, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
     SMIN_LAUNCH_CHECK();
     const int slab_sz = 64 * dl + dl + 32;
-    hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, ws, row_ptr, L, dl, Nq, cpr, dMq, dwhat, dshat, duq);
+    hipLaunchKernelGGL(content_attn_reduce_kernel, dim3(cdiv(slab_sz, 256), B), dim3(256), 0, st, ws, row_ptr, L, dl, Nq, cpr, WS - 4, dMq, dwhat, dshat, duq);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
