@@ -76,6 +76,10 @@ struct RowGeom {
 // and the P / dS accumulators feed the next MFMA as B operands without any data movement.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products, block b = lanes 4b .. 4b+3: lane 4b + j, register i gets
+// a[lane 4b + i] * b[lane 4b + j] (layout confirmed on gfx950 by tools/mfma4x4_probe.hip).  Two passes (8 cycles): a quarter of a
+// 16x16x4 step for the same FLOPs, all of them useful when only four words are contracted.
+__device__ __forceinline__ f32x4v mfma4(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 // all-reduce over the four lane groups kg (lanes n, n+16, n+32, n+48) in registers: gfx950's v_permlane16_swap /
 // v_permlane32_swap exchange 16- and 32-lane rows without the LDS crossbar a __shfl_xor goes through.  Every lane ends with
 // the same bits: (r0 op r1) op (r2 op r3).
@@ -121,6 +125,26 @@ __device__ __forceinline__ void mask_rows16(float (&v)[DL / 16][4], const float4
     }
 }
 
+// Words 16 .. 19 (the only valid slots of block 1 when 16 < Nq <= 20) against the rows v of a tile: out[i] = <X[word 16 + i], v[row]>
+// for the lane's own row.  A block of the 4x4x1 MFMA is the four clips of a cell at one lane group kg: the a operand is the word
+// image (lane & 3 picks the word: slot 16 + 4 (lane & 3) of the slot-major image), the b operand the lane's own row value, and each
+// lane group contracts its own features; kg_sum adds the four partial sums.  32 two-pass MFMAs instead of 32 eight-pass ones
+// of which 12 of 16 output rows were padding.
+template <int DL>
+__device__ __forceinline__ f32x4v extra_words_partial(f32x4v acc, int j, const float (&v)[4], const float* sX, int lane)
+{
+    constexpr int LDM = DL + 4;
+    const float4 a = ldg4(sX + (16 + 4 * (lane & 3)) * LDM + 16 * j + 4 * (lane >> 4));
+    acc = mfma4(a.x, v[0], acc); acc = mfma4(a.y, v[1], acc); acc = mfma4(a.z, v[2], acc); acc = mfma4(a.w, v[3], acc);
+    return acc;
+}
+// every lane: the four totals; lane group kg keeps word 16 + kg (its slot 16 + 4 kg + 0)
+__device__ __forceinline__ float extra_words_select(f32x4v acc, int kg)
+{
+    const float t0 = kg_sum(acc[0]), t1 = kg_sum(acc[1]), t2 = kg_sum(acc[2]), t3 = kg_sum(acc[3]);
+    return kg == 0 ? t0 : (kg == 1 ? t1 : (kg == 2 ? t2 : t3));
+}
+
 // P[4b + r] = softmax over words of row n, slot 16b + 4kg + r.  sM: [32 slots][LDM] (A operand: lane l15 = slot in block)
 // WS = number of 4-word contraction steps the kernel is built for (>= ceil(Nq / 4)): compile-time, so that no MFMA sits
 // behind a branch on Nq (hipcc turns `if (Nq > ..) mfma` into a basic block per MFMA and stops scheduling across them).
@@ -136,12 +160,14 @@ __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch
     for (int j = 0; j < DL / 16; ++j) {
         const float4 a0 = ldg4(sM + l15 * LDM + 16 * j + 4 * kg);
         S0 = mfma16(a0.x, ch[j][0], S0); S0 = mfma16(a0.y, ch[j][1], S0); S0 = mfma16(a0.z, ch[j][2], S0); S0 = mfma16(a0.w, ch[j][3], S0);
-        if (WS > 4) {
+        if (WS == 5) S1 = extra_words_partial<DL>(S1, j, ch[j], sM, lane);
+        else if (WS > 4) {
             const float4 a1 = ldg4(sM + (16 + l15) * LDM + 16 * j + 4 * kg);
             S1 = mfma16(a1.x, ch[j][0], S1); S1 = mfma16(a1.y, ch[j][1], S1); S1 = mfma16(a1.z, ch[j][2], S1); S1 = mfma16(a1.w, ch[j][3], S1);
         }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    if (WS == 5) { const float s1 = extra_words_select(S1, kg); S1[0] = s1; S1[1] = 0.f; S1[2] = 0.f; S1[3] = 0.f; }      // slots 16 + 4kg + r, r > 0: words >= 20
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -236,37 +262,39 @@ __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&c
 // Stage one sample's word-side operands in slot order.  All global loads of the pass are issued before the first LDS store
 // (unconditional, clamped addresses; invalid slots / features become zeros).  NT threads.
 //   sM / sW : [32 slots][LDM]   (float4 along features)      sMT / sWT : [DLP features][LDW]   (slot-contiguous)
+// (tid = threadIdx.x, handed in so that a caller can hide it from loop-invariant code motion: hoisted out of the segment loop the
+//  clamped indices and predicates of the staging passes stay live for the whole kernel -- dozens of registers, spilled)
 template <int DL, int NT>
-__device__ __forceinline__ void stage_slot_major(float* sA, const float* src, int b, int dl, int Nq)
+__device__ __forceinline__ void stage_slot_major(float* sA, const float* src, int b, int dl, int Nq, int tid)
 {
     constexpr int LDM = DL + 4, Q = DL / 4, TOT = 32 * Q, IT = (TOT + NT - 1) / NT;
     float4 v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int idx = min((int)threadIdx.x + NT * it, TOT - 1), sl = idx / Q, d = (idx % Q) * 4;
+        const int idx = min(tid + NT * it, TOT - 1), sl = idx / Q, d = (idx % Q) * 4;
         const int w = min(slot_word(sl), Nq - 1);
         v[it] = ldg4(src + ((size_t)b * Nq + w) * dl + min(d, dl - 4));
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int idx = (int)threadIdx.x + NT * it, sl = idx / Q, d = (idx % Q) * 4;
+        const int idx = tid + NT * it, sl = idx / Q, d = (idx % Q) * 4;
         if (idx < TOT) stg4(sA + sl * LDM + d, f4sel(slot_word(sl) < Nq && d < dl, v[it]));
     }
 }
 template <int DL, int NT>
-__device__ __forceinline__ void stage_feature_major(float* sT, const float* src, int b, int dl, int Nq)
+__device__ __forceinline__ void stage_feature_major(float* sT, const float* src, int b, int dl, int Nq, int tid)
 {
     constexpr int Q = DL / 4, TOT = 32 * Q, IT = (TOT + NT - 1) / NT;
     float4 v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {                             // slot fastest: the transposed scalar stores are conflict-free
-        const int idx = min((int)threadIdx.x + NT * it, TOT - 1), sl = idx & 31, d = (idx >> 5) * 4;
+        const int idx = min(tid + NT * it, TOT - 1), sl = idx & 31, d = (idx >> 5) * 4;
         const int w = min(slot_word(sl), Nq - 1);
         v[it] = ldg4(src + ((size_t)b * Nq + w) * dl + min(d, dl - 4));
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int idx = (int)threadIdx.x + NT * it, sl = idx & 31, d = (idx >> 5) * 4;
+        const int idx = tid + NT * it, sl = idx & 31, d = (idx >> 5) * 4;
         if (idx < TOT) {
             const float4 x = f4sel(slot_word(sl) < Nq && d < dl, v[it]);
             sT[(d + 0) * LDW + sl] = x.x; sT[(d + 1) * LDW + sl] = x.y; sT[(d + 2) * LDW + sl] = x.z; sT[(d + 3) * LDW + sl] = x.w;
@@ -274,9 +302,9 @@ __device__ __forceinline__ void stage_feature_major(float* sT, const float* src,
     }
 }
 template <int DL, int NT>
-__device__ __forceinline__ void stage_vectors(float* sS, float* sU, float* sQ, const float* shat, const float* uq, const float* qmask, int b, int dl, int Nq)
+__device__ __forceinline__ void stage_vectors(float* sS, float* sU, float* sQ, const float* shat, const float* uq, const float* qmask, int b, int dl, int Nq, int tid)
 {
-    const int t = threadIdx.x;
+    const int t = tid;
     for (int d = t; d < DL; d += NT) sS[d] = d < dl ? shat[(size_t)b * dl + d] : 0.f;
     if (t < 32) {
         const int w = slot_word(t);
@@ -313,9 +341,11 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
         const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
         const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
         __syncthreads();                                          // the previous segment's tiles are done with the LDS images
-        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq);
-        stage_feature_major<DL, 256>(sWT, what, b, dl, Nq);
-        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                             // not loop-invariant as far as the compiler knows (see stage_slot_major)
+        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq, tid);
+        stage_feature_major<DL, 256>(sWT, what, b, dl, Nq, tid);
+        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq, tid);
         __syncthreads();
 
         int n0 = n + 4 * wave;
@@ -388,6 +418,13 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
 // of block 1 as column 16 + kg (WS - 4) + r; columns past that read the next row (finite garbage) and their results are dropped.
 // Per (range, sample) segment the accumulators go to slab[range + sample]:  [dM 32 x dl | dW 32 x dl | dshat dl | du 32]
 // in column order; content_attn_reduce_kernel sums a sample's slabs in range order (fixed order: deterministic).
+#ifdef SMIN_ATTN_STAMPS
+// diagnostic build only (tools/attn_stamps.sh): s_memtime at the phase boundaries of a few rounds of two workgroups
+__device__ unsigned long long g_attn_stamps[2 * 4 * 8 * 16];
+#define STAMP(k) do { if (stamp_on && (unsigned)stamp_round < 8u) { g_attn_stamps[((stamp_blk * 4 + wave) * 8 + stamp_round) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 template <int WS> constexpr int bwd_ldp() { return WS <= 5 ? 20 : (WS == 6 ? 28 : 36); }
 template <int WS> constexpr int bwd_ncols() { return 16 + 4 * (WS - 4); }
 template <int DL, int WS>
@@ -397,6 +434,59 @@ __device__ __host__ __forceinline__ int col_word(int c, int nb1) {
     if (c < 16) return 4 * (c & 3) + (c >> 2);
     const int e = c - 16, d = nb1 > 0 ? nb1 : 1;
     return 16 + 4 * (e % d) + e / d;
+}
+
+// geometry of a tile without its mask load (the mask is requested with the prefetched rows: nothing waits for it before the stores)
+__device__ __forceinline__ RowGeom row_geom16_nm(int n0, int n_end, int C, int lane, int& cellc) {
+    const int j = lane & 15, cell = n0 + (j >> 2), c = j & 3;
+    RowGeom g;
+    g.ok = cell < n_end && c < C;
+    cellc = g.ok ? cell : n_end - 1;
+    g.row = cellc * C + (g.ok ? c : 0);
+    g.m = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) g.nbok[o] = (c ^ o) < C;
+    return g;
+}
+
+// One reduction phase of a round: wave fq adds the 64 rows of the round to its [columns] x [features 32fq .. 32fq+31] block of
+// dwhat = P^T da (KIND 1, + dshat = colsum da) or dMq = dS^T chat (KIND 0, + duq = colsum dS).  Column block 0 (16 slots) runs on
+// v_mfma_f32_16x16x4_f32 (a = tile value [row 4t + kg][column l15], b = X[row 4t + kg][feature l15]; result register r of lane
+// (feature l15, kg) = [column 4kg + r][feature]); with 16 < Nq <= 20 the four extra columns are four FMAs per step against the
+// b value the lane already holds (the 32x32x2 MFMA of the first version spent 12 of its 32 columns on padding), with more
+// words a second column block.  HOOK(t) is called once per step t = 0 .. 15: the next round's row loads are spread over the loop.
+template <int KIND, int DL, int WS, class HOOK>
+__device__ __forceinline__ void reduce_round(f32x4v (&rA)[2][2], float (&rE)[2][4], float (&cs)[2], float& csa, float& csb, float (&csx)[4],
+                                             const float* T, const float* X, int fq, int lane, HOOK hook)
+{
+    constexpr int LDA = DL + 4, LDP = bwd_ldp<WS>(), NB1 = WS - 4;
+    constexpr bool TWO = NB1 >= 2, XV = NB1 == 1;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const float* Tr = T + kg * LDP;
+    const float* X0 = X + kg * LDA + min(32 * fq + l15, DL - 1);
+    const float* X1 = X + kg * LDA + min(32 * fq + 16 + l15, DL - 1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        hook(t);
+        const float a0 = Tr[4 * t * LDP + l15];
+        const float x0 = X0[4 * t * LDA], x1 = X1[4 * t * LDA];
+        rA[0][0] = mfma16(a0, x0, rA[0][0]);
+        rA[0][1] = mfma16(a0, x1, rA[0][1]);
+        if (TWO) {
+            const float a1 = Tr[4 * t * LDP + 16 + l15];
+            rA[1][0] = mfma16(a1, x0, rA[1][0]);
+            rA[1][1] = mfma16(a1, x1, rA[1][1]);
+            if (KIND == 0) csb += a1;
+        }
+        if (XV) {
+            const float4 pv = ldg4(Tr + 4 * t * LDP + 16);
+            rE[0][0] = fmaf(pv.x, x0, rE[0][0]); rE[0][1] = fmaf(pv.y, x0, rE[0][1]); rE[0][2] = fmaf(pv.z, x0, rE[0][2]); rE[0][3] = fmaf(pv.w, x0, rE[0][3]);
+            rE[1][0] = fmaf(pv.x, x1, rE[1][0]); rE[1][1] = fmaf(pv.y, x1, rE[1][1]); rE[1][2] = fmaf(pv.z, x1, rE[1][2]); rE[1][3] = fmaf(pv.w, x1, rE[1][3]);
+            if (KIND == 0) { csx[0] += pv.x; csx[1] += pv.y; csx[2] += pv.z; csx[3] += pv.w; }
+        }
+        if (KIND == 1) { cs[0] += x0; cs[1] += x1; } else csa += a0;
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int DL, int WS, bool MEAN2, bool PERCELL>
@@ -411,6 +501,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int LDM = DL + 4, KJ = DL / 16, LDA = DL + 4, DT = (DL + 31) / 32, LDP = bwd_ldp<WS>(), NB1 = WS - 4, NCOLS = bwd_ncols<WS>();
+    constexpr bool TWO = NB1 >= 2, XV = NB1 == 1;
     float* sM = smem_dyn; float* sW = sM + 32 * LDM; float* sS = sW + 32 * LDM; float* sU = sS + DL; float* sQ = sU + 32;
     float* X = sQ + 32; float* tDs = X + 64 * LDA; float* tP = tDs + 64 * LDP;
     const int rg = blockIdx.x;
@@ -418,41 +509,63 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
     if (n_lo >= N) return;
     const int n_hi = min(N, n_lo + cells_per_range);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kg = lane >> 4, l15 = lane & 15;
-    const int fq = wave, l31 = lane & 31, h = lane >> 5;
+    const int fq = wave;
     const size_t slab_sz = (size_t)64 * dl + dl + 32;
-    if (threadIdx.x < 32) tP[64 * LDP + threadIdx.x] = 0.f;       // the slack the last row's dropped columns read
+    if (threadIdx.x < 32) tP[64 * LDP + threadIdx.x] = 0.f;       // slack behind the tiles (a b128 read of the last row's extra columns ends here)
     float* myX = X + (16 * wave + l15) * LDA;
+#ifdef SMIN_ATTN_STAMPS
+    const bool stamp_on = (rg == 3 || rg == 300) && lane == 0;
+    const int stamp_blk = rg == 3 ? 0 : 1;
+    int stamp_round = -3;                                         // the first two rounds are not recorded
+#endif
 
     for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
         const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
         const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
         __syncthreads();
-        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq);
-        stage_slot_major<DL, 256>(sW, what, b, dl, Nq);
-        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                             // not loop-invariant as far as the compiler knows (see stage_slot_major)
+        stage_slot_major<DL, 256>(sM, Mq, b, dl, Nq, tid);
+        stage_slot_major<DL, 256>(sW, what, b, dl, Nq, tid);
+        stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq, tid);
         __syncthreads();
-        f32x16 racc0, racc1;
+        // accumulators of the segment, [kind][column block][feature block]; rE: the four extra columns; cs*: column sums
+        f32x4v rA0[2][2], rA1[2][2];
+        float rE0[2][4], rE1[2][4], cs1[2] = {0.f, 0.f}, cs0a = 0.f, cs0b = 0.f, cs0x[4] = {0.f, 0.f, 0.f, 0.f}, csdummy[2] = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { racc0[r] = 0.f; racc1[r] = 0.f; }
-        float cs0 = 0.f, cs1 = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rA0[i][k][r] = 0.f; rA1[i][k][r] = 0.f; rE0[i][r] = 0.f; rE1[i][r] = 0.f; }
+            }
 
-        // the rows of a round (chat, output gradients) are requested one round ahead, before the previous round's reduction
+        // the rows of a round (chat, output gradients) are requested one round ahead, spread over the previous round's reduction
         // phases, so that their HBM latency hides behind them
         float4 raw[KJ], gq[KJ], gm[KJ];
-        RowGeom g = row_geom16(cells, n + 4 * wave, seg_end, C, lane);
+        int cellc, mraw;
+        RowGeom g = row_geom16_nm(n + 4 * wave, seg_end, C, lane, cellc);
+        mraw = cells[4 * (size_t)cellc + 3];
         fetch_rows16<DL>(raw, chat, g.row, dl, kg);
         fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
         if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
 
         for (int c0 = n; c0 < seg_end; c0 += 16) {                // rounds
             float ch[KJ][4];
+#ifdef SMIN_ATTN_STAMPS
+            ++stamp_round;
+#endif
+            STAMP(0);
             {
                 float P[8], Ao[4];
                 mask_rows16<DL>(ch, raw, g.ok, dl, kg);
+                g.m = g.ok ? (float)mraw : 0.f;                     // requested a round ago with the rows
                 __builtin_amdgcn_sched_barrier(0);                  // the prefetched registers die here
                 scores_softmax16<DL, WS>(P, ch, sM, sU, sQ, Nq, scale, lane);
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(1);
                 __syncthreads();                                    // the previous round's R0 is done with X / tDs (first writes below)
+                STAMP(2);
                 clip_attention16<DL>(Ao, ch, sS, g, scale, lane, [&](int j) {
                     f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
                     const f32x4v acc = words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
@@ -460,6 +573,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     return acc;
                 });
 
+                STAMP(3);
                 // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
                 float dch[KJ][4];
                 float dAo[4] = {0.f, 0.f, 0.f, 0.f};
@@ -485,6 +599,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(4);
                 // A = softmax(Z) * m ; Z symmetric in (c, c')
                 float sym[4];
                 {
@@ -521,12 +636,15 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     stg4(myX + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
                     const float4 w0 = ldg4(sW + l15 * LDM + d);
                     dP0 = mfma16(w0.x, da4[0], dP0); dP0 = mfma16(w0.y, da4[1], dP0); dP0 = mfma16(w0.z, da4[2], dP0); dP0 = mfma16(w0.w, da4[3], dP0);
-                    if (WS > 4) {
+                    if (WS == 5) dP1 = extra_words_partial<DL>(dP1, j, da4, sW, lane);
+                    else if (WS > 4) {
                         const float4 w1 = ldg4(sW + (16 + l15) * LDM + d);
                         dP1 = mfma16(w1.x, da4[0], dP1); dP1 = mfma16(w1.y, da4[1], dP1); dP1 = mfma16(w1.z, da4[2], dP1); dP1 = mfma16(w1.w, da4[3], dP1);
                     }
                     if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
+                if (WS == 5) { const float d1 = extra_words_select(dP1, kg); dP1[0] = d1; dP1[1] = 0.f; dP1[2] = 0.f; dP1[3] = 0.f; }
+                STAMP(5);
                 // P = softmax(S), S = (raw + u) * scale * qmask
                 float pd = 0.f;
 #pragma unroll
@@ -552,66 +670,92 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(6);
                 // raw = chat Mq^T :  dchat^T[d][n] += sum_slots Mq[slot][d] dS^T[slot][n]   -> dchat = (...) * m   (chat = linear(fc) * m)
+                const float gm_ = g.m;
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     f32x4v acc = {dch[j][0], dch[j][1], dch[j][2], dch[j][3]};
                     acc = words_tile16_S<LDM, WS>(acc, j, dS, sM, lane);
                     const int d = 16 * j + 4 * kg;
-                    if (g.ok && d < dl) stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[0] * g.m, acc[1] * g.m, acc[2] * g.m, acc[3] * g.m));
+                    if (g.ok && d < dl) stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[0] * gm_, acc[1] * gm_, acc[2] * gm_, acc[3] * gm_));
                     if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // next round's chat rows (past the segment: clamped to its last row, never used)
-            g = row_geom16(cells, c0 + 16 + 4 * wave, seg_end, C, lane);
-            fetch_rows16<DL>(raw, chat, g.row, dl, kg);
-            const int feat = 32 * fq + l31;
-            const float* Bt = X + h * LDA + min(feat, DL - 1);
+            STAMP(7);
+            // next round's rows (past the segment: clamped to its last row, never used): requested inside the reduction loops below
+            g = row_geom16_nm(c0 + 16 + 4 * wave, seg_end, C, lane, cellc);
+            const float* nx_chat = chat + (size_t)g.row * dl;
+            const float* nx_g = dcchat + (size_t)(PERCELL ? g.row / C : g.row) * dl;
+            const float* nx_m = dmean2 + (size_t)(g.row / C) * dl;
+            STAMP(8);
             __syncthreads();                                        // the round's da / dS / P rows are in LDS
-            if (fq < DT) {                                          // R1: dwhat += P^T da, dshat += colsum da
-                const float* At = tP + h * LDP + l31;
-#pragma unroll 8
-                for (int s2 = 0; s2 < 32; ++s2) {
-                    const float bv = Bt[2 * s2 * LDA];
-                    racc1 = mfma32(At[2 * s2 * LDP], bv, racc1);
-                    cs1 += bv;
-                }
+            STAMP(9);
+            if (fq < DT) {                                          // R1: dwhat += P^T da, dshat += colsum da; the chat rows of the next round
+                float dcsa = 0.f, dcsb = 0.f, dcsx[4] = {0.f, 0.f, 0.f, 0.f};
+                reduce_round<1, DL, WS>(rA1, rE1, cs1, dcsa, dcsb, dcsx, tP, X, fq, lane, [&](int t) {
+                    if (t == 0) mraw = cells[4 * (size_t)cellc + 3];
+                    if ((t & 1) == 0 && t / 2 < KJ) raw[t / 2] = ldg4(nx_chat + min(16 * (t / 2) + 4 * kg, dl - 4));
+                });
+            } else {
+                mraw = cells[4 * (size_t)cellc + 3];
+                fetch_rows16<DL>(raw, chat, g.row, dl, kg);
             }
+            STAMP(10);
             __syncthreads();                                        // every wave is done with the da rows
+            STAMP(11);
 #pragma unroll
             for (int j = 0; j < KJ; ++j) stg4(myX + 16 * j + 4 * kg, make_float4(ch[j][0], ch[j][1], ch[j][2], ch[j][3]));      // W
-            // next round's gradient rows: requested now that the chat registers are free, consumed a third into the tile phase
-            fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
-            if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
+            STAMP(12);
             __syncthreads();
-            if (fq < DT) {                                          // R0: dMq += dS^T chat, duq += colsum dS
-                const float* At = tDs + h * LDP + l31;
-#pragma unroll 8
-                for (int s2 = 0; s2 < 32; ++s2) {
-                    const float av = At[2 * s2 * LDP];
-                    racc0 = mfma32(av, Bt[2 * s2 * LDA], racc0);
-                    cs0 += av;
-                }
+            STAMP(13);
+            if (fq < DT) {                                          // R0: dMq += dS^T chat, duq += colsum dS; the gradient rows of the next round
+                reduce_round<0, DL, WS>(rA0, rE0, csdummy, cs0a, cs0b, cs0x, tDs, X, fq, lane, [&](int t) {
+                    if ((t & 1) == 0 && t / 2 < KJ) gq[t / 2] = ldg4(nx_g + min(16 * (t / 2) + 4 * kg, dl - 4));
+                    if (MEAN2 && (t & 1) == 1 && t / 2 < KJ) gm[t / 2] = ldg4(nx_m + min(16 * (t / 2) + 4 * kg, dl - 4));
+                });
+            } else {
+                fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
+                if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
             }
+            STAMP(14);
         }
-        // the segment's partial result
+        // the segment's partial result: slab rows are tile columns (content_attn_reduce_kernel maps them to words)
         float* sl = slab + (size_t)(rg + b) * slab_sz;
+        asm volatile("" : "+v"(sl));                              // the store addresses below are formed here, not ahead of the segment loop
         if (fq < DT) {
-            const int feat = 32 * fq + l31;
-            if (feat < dl) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = wmap(r, h);
-                    if (col < NCOLS) {
-                        sl[(size_t)col * dl + feat] = racc0[r];
-                        sl[(size_t)(32 + col) * dl + feat] = racc1[r];
+            for (int fb = 0; fb < 2; ++fb) {
+                const int feat = 32 * fq + 16 * fb + l15;
+                const bool fok = feat < dl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 4 * kg + r;
+                    if (fok) {
+                        sl[(size_t)col * dl + feat] = rA0[0][fb][r];
+                        sl[(size_t)(32 + col) * dl + feat] = rA1[0][fb][r];
+                        if (TWO && 16 + col < NCOLS) {
+                            sl[(size_t)(16 + col) * dl + feat] = rA0[1][fb][r];
+                            sl[(size_t)(48 + col) * dl + feat] = rA1[1][fb][r];
+                        }
+                    }
+                    if (XV) {                                       // extra column 16 + r: partial sums of the four lane groups
+                        const float e0 = kg_sum(rE0[fb][r]), e1 = kg_sum(rE1[fb][r]);
+                        if (fok && kg == 0) { sl[(size_t)(16 + r) * dl + feat] = e0; sl[(size_t)(48 + r) * dl + feat] = e1; }
                     }
                 }
+                const float c1 = kg_sum(cs1[fb]);
+                if (fok && kg == 0) sl[(size_t)64 * dl + feat] = c1;
             }
-            const float c1 = cs1 + __shfl_xor(cs1, 32), c0s = cs0 + __shfl_xor(cs0, 32);
-            if (h == 0) {
-                if (feat < dl) sl[(size_t)64 * dl + feat] = c1;
-                if (fq == 0) sl[(size_t)64 * dl + dl + l31] = c0s;
+            // duq: column sums of dS (every wave holds the same sums: wave 0 writes)
+            const float ca = kg_sum(cs0a), cb = kg_sum(cs0b);
+            float cx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cx[r] = kg_sum(cs0x[r]);
+            if (fq == 0 && kg == 0) {
+                sl[(size_t)64 * dl + dl + l15] = ca;
+                if (TWO) sl[(size_t)64 * dl + dl + 16 + l15] = cb;
+                if (XV && l15 < 4) sl[(size_t)64 * dl + dl + 16 + l15] = l15 == 0 ? cx[0] : (l15 == 1 ? cx[1] : (l15 == 2 ? cx[2] : cx[3]));
             }
         }
         n = seg_end;
@@ -801,6 +945,14 @@ extern "C" int smin_content_attn_fwd_cch(void* stream, const float* chat, const 
     SMIN_REQUIRE(cc_h && ccmean);
     return launch_content_attn_fwd_h((hipStream_t)stream, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_h, ccmean, dl, Nq);
 }
+
+#ifdef SMIN_ATTN_STAMPS
+extern "C" int smin_debug_attn_stamps(unsigned long long* host_out, int n)
+{
+    if (n > 2 * 4 * 8 * 16) n = 2 * 4 * 8 * 16;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" size_t smin_content_attn_bwd_workspace_bytes(int N, int B, int C, int dl)
 {
