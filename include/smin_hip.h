@@ -12,7 +12,7 @@
  *   - all calls are asynchronous on `stream`, allocate nothing and never synchronise (graph-capturable);
  *     scratch comes from the caller-provided workspace `ws` (size from smin_workspace_bytes).
  *   - return 0 on success, a positive hipError_t, or a negative code for a rejected argument.
- *   - requirements: D % 4 == 0, dl % 8 == 0, dl <= 128, 2 <= C <= 4, Nq <= 32.
+ *   - requirements: D % 4 == 0, dl % 16 == 0, 16 <= dl <= 128, 2 <= C <= 4, Nq <= 32.
  *
  * Packed valid-cell layout: the L x L map is stored as a list of N cells sorted by
  * (b, i, j):  cells[n] = {b, i, j, m} (int32 x4, m = moment_mask[b,i,j]);

@@ -43,7 +43,7 @@ template <> __device__ __forceinline__ float nb<3>(float v) { return qperm<0x1B>
 // otherwise materialises all neighbour values of a whole tile first (hundreds of live VGPRs, scratch spills).
 // The leading s_nop 1 covers the "VALU write -> DPP read" hazard for x (asm is not padded by the compiler).
 __device__ __forceinline__ void fmac_nb3(float& a1, float& a2, float& a3, float x, float y1, float y2, float y3) {
-    asm volatile("s_nop 1\n\t"
+    asm("s_nop 1\n\t"
                  "v_fmac_f32_dpp %0, %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_fmac_f32_dpp %1, %3, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_fmac_f32_dpp %2, %3, %6 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
@@ -51,7 +51,7 @@ __device__ __forceinline__ void fmac_nb3(float& a1, float& a2, float& a3, float 
 }
 // acc += sum_{o=1..3} nb<o>(x) * y_o
 __device__ __forceinline__ void fmac_nb_sum(float& acc, float x, float y1, float y2, float y3) {
-    asm volatile("s_nop 1\n\t"
+    asm("s_nop 1\n\t"
                  "v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_fmac_f32_dpp %0, %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_fmac_f32_dpp %0, %1, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
@@ -114,13 +114,13 @@ __device__ __forceinline__ RowGeom row_geom16(const int* cells, int n0, int n_en
 template <int DL>
 __device__ __forceinline__ void fetch_rows16(float4 (&v)[DL / 16], const float* src, int row, int dl, int kg) {
 #pragma unroll
-    for (int j = 0; j < DL / 16; ++j) v[j] = ldg4(src + (size_t)row * dl + min(16 * j + 4 * kg, dl - 4));
+    for (int j = 0; j < DL / 16; ++j) v[j] = ldg4(src + (size_t)row * dl + 4 * kg + min(16 * j, dl - 16));      // dl % 16 == 0: a uniform clamp
 }
 template <int DL>
 __device__ __forceinline__ void mask_rows16(float (&v)[DL / 16][4], const float4 (&x)[DL / 16], bool rok, int dl, int kg) {
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
-        const bool ok = rok && 16 * j + 4 * kg < dl;
+        const bool ok = rok && 16 * j < dl;
         v[j][0] = ok ? x[j].x : 0.f; v[j][1] = ok ? x[j].y : 0.f; v[j][2] = ok ? x[j].z : 0.f; v[j][3] = ok ? x[j].w : 0.f;
     }
 }
@@ -155,18 +155,20 @@ __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch
 {
     constexpr int LDM = DL + 4;
     const int l15 = lane & 15, kg = lane >> 4;
-    f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
+    // two accumulators per block, alternating: a dependent 16x16x4 MFMA issues 40 cycles after its predecessor, an independent one 32
+    f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S0b = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f}, S1b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
         const float4 a0 = ldg4(sM + l15 * LDM + 16 * j + 4 * kg);
-        S0 = mfma16(a0.x, ch[j][0], S0); S0 = mfma16(a0.y, ch[j][1], S0); S0 = mfma16(a0.z, ch[j][2], S0); S0 = mfma16(a0.w, ch[j][3], S0);
-        if (WS == 5) S1 = extra_words_partial<DL>(S1, j, ch[j], sM, lane);
+        S0 = mfma16(a0.x, ch[j][0], S0); S0b = mfma16(a0.y, ch[j][1], S0b); S0 = mfma16(a0.z, ch[j][2], S0); S0b = mfma16(a0.w, ch[j][3], S0b);
+        if (WS == 5) { if (j & 1) S1b = extra_words_partial<DL>(S1b, j, ch[j], sM, lane); else S1 = extra_words_partial<DL>(S1, j, ch[j], sM, lane); }
         else if (WS > 4) {
             const float4 a1 = ldg4(sM + (16 + l15) * LDM + 16 * j + 4 * kg);
             S1 = mfma16(a1.x, ch[j][0], S1); S1 = mfma16(a1.y, ch[j][1], S1); S1 = mfma16(a1.z, ch[j][2], S1); S1 = mfma16(a1.w, ch[j][3], S1);
         }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    S0 += S0b; S1 += S1b;
     if (WS == 5) { const float s1 = extra_words_select(S1, kg); S1[0] = s1; S1[1] = 0.f; S1[2] = 0.f; S1[3] = 0.f; }      // slots 16 + 4kg + r, r > 0: words >= 20
     float mx = -INFINITY;
 #pragma unroll
@@ -224,6 +226,58 @@ __device__ __forceinline__ f32x4v words_tile16_S(f32x4v acc, int j, const float 
     return acc;
 }
 
+// The same contraction for two adjacent blocks j0, j0 + 1 in three steps a caller can pipeline: (1) request every word operand of
+// both blocks, (2) pin: one wait for the whole batch instead of a read -> wait -> MFMA round trip per step (hipcc, short of
+// registers, sinks each LDS read to its use), (3) the two dependent MFMA chains interleaved.
+template <int LDM, int WS>
+__device__ __forceinline__ void words_pair_load(float (&wa)[WS], float (&wb)[WS], int j0, const float* sX, int lane)
+{
+    const float* base = sX + (4 * (lane >> 4)) * LDM + 16 * j0 + (lane & 15);
+#pragma unroll
+    for (int s2 = 0; s2 < WS; ++s2) { const int row = 16 * (s2 >> 2) + (s2 & 3); wa[s2] = base[row * LDM]; wb[s2] = base[row * LDM + 16]; }
+}
+template <int WS>
+__device__ __forceinline__ void words_pair_pin(float (&wa)[WS], float (&wb)[WS])
+{
+#pragma unroll
+    for (int s2 = 0; s2 < WS; ++s2) { asm volatile("" : "+v"(wa[s2])); asm volatile("" : "+v"(wb[s2])); }
+}
+template <int WS>
+__device__ __forceinline__ void words_pair_mfma(f32x4v& accA, f32x4v& accB, const float (&wa)[WS], const float (&wb)[WS], const float (&V)[8])
+{
+#pragma unroll
+    for (int s2 = 0; s2 < WS; ++s2) { accA = mfma16(wa[s2], V[s2], accA); accB = mfma16(wb[s2], V[s2], accB); }
+}
+
+// The 4 x 4 clip-by-clip products of a cell on the 4x4x1 MFMA: with a = x, b = y of the same lane, register i of lane (.., clip c)
+// accumulates x_i y_c over the lane's features, i.e. D[i] = <x_i, y_c> for the lane group's share of the features.  The per-clip
+// code wants the neighbour order out[o] = D[c ^ o]: eight selects on the two clip bits.  (As three fused DPP FMAs per feature
+// the same sums cost 4 vector instructions + a hazard nop per feature; here one two-pass MFMA.)
+__device__ __forceinline__ void quad_neighbour_order(float (&out)[4], f32x4v D, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float t0 = b0 ? D[1] : D[0], t1 = b0 ? D[0] : D[1], t2 = b0 ? D[3] : D[2], t3 = b0 ? D[2] : D[3];
+    out[0] = b1 ? t2 : t0; out[1] = b1 ? t3 : t1; out[2] = b1 ? t0 : t2; out[3] = b1 ? t1 : t3;
+}
+
+// z[o] = <q_c, q_{c^o}> partial sums of the lane group -> Ao[o] = softmax over the clips present, times the cell mask
+__device__ __forceinline__ void clip_softmax(float (&Ao)[4], float (&z)[4], const RowGeom& g, float scale)
+{
+    float mx = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        z[o] = kg_sum(z[o]) * scale;
+        z[o] = g.nbok[o] ? z[o] : -INFINITY;
+        mx = fmaxf(mx, z[o]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { Ao[o] = expf(z[o] - mx); den += Ao[o]; }
+    const float inv = g.m / den;                                  // models.py:262-263: softmax, then * mask
+#pragma unroll
+    for (int o = 0; o < 4; ++o) Ao[o] *= inv;
+}
+
 // clip self-attention of a tile: Ao[o] = softmax_c'(q_c . q_c') * m for neighbour c' = c ^ o.  ATT(j) returns a^T block j.
 template <int DL, class ATT>
 __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&ch)[DL / 16][4], const float* sS, const RowGeom& g, float scale,
@@ -244,19 +298,57 @@ __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&c
         }
         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
-    float mx = -INFINITY;
+    clip_softmax(Ao, z, g, scale);
+}
+
+// backward form: the a^T blocks come in pairs (words_pair_*), the next pair's word operands are requested while this pair's
+// scores are formed, and every block is parked in the lane's own row of X (myX) for the dq pass.
+template <int DL, int WS>
+__device__ __forceinline__ void clip_attention16_bwd(float (&Ao)[4], const float (&ch)[DL / 16][4], const float (&P)[8], const float* sW, const float* sS,
+                                                     float* myX, const RowGeom& g, float scale, int lane)
+{
+    constexpr int LDM = DL + 4, KJ = DL / 16;
+    const int kg = lane >> 4;
+    f32x4v Z = {0.f, 0.f, 0.f, 0.f}, Zb = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KJ >= 2) {
+        float wa[2][WS], wb[2][WS];
+        words_pair_load<LDM, WS>(wa[0], wb[0], 0, sW, lane);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        z[o] = kg_sum(z[o]) * scale;
-        z[o] = g.nbok[o] ? z[o] : -INFINITY;
-        mx = fmaxf(mx, z[o]);
+        for (int jp = 0; jp < KJ / 2; ++jp) {
+            const int cur = jp & 1;
+            words_pair_pin<WS>(wa[cur], wb[cur]);
+            f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            words_pair_mfma<WS>(acc[0], acc[1], wa[cur], wb[cur], P);
+            if (jp + 1 < KJ / 2) words_pair_load<LDM, WS>(wa[cur ^ 1], wb[cur ^ 1], 2 * jp + 2, sW, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * jp + u;
+                const float4 sh = ldg4(sS + 16 * j + 4 * kg);
+                const float tq[4] = {acc[u][0] + sh.x, acc[u][1] + sh.y, acc[u][2] + sh.z, acc[u][3] + sh.w};
+                stg4(myX + 16 * j + 4 * kg, make_float4(tq[0], tq[1], tq[2], tq[3]));      // a + shat, parked for the dq pass
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float qv = ch[j][q] * tq[q];
+                    if (u) Zb = mfma4(qv, qv, Zb); else Z = mfma4(qv, qv, Z);
+                }
+            }
+        }
+    } else {
+        f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4v acc = words_tile16_S<LDM, WS>(z4, 0, P, sW, lane);
+        const float4 sh = ldg4(sS + 4 * kg);
+        const float tq[4] = {acc[0] + sh.x, acc[1] + sh.y, acc[2] + sh.z, acc[3] + sh.w};
+        stg4(myX + 4 * kg, make_float4(tq[0], tq[1], tq[2], tq[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float qv = ch[0][q] * tq[q];
+            Z = mfma4(qv, qv, Z);
+        }
     }
-    float den = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) { Ao[o] = expf(z[o] - mx); den += Ao[o]; }
-    const float inv = g.m / den;                                  // models.py:262-263: softmax, then * mask
-#pragma unroll
-    for (int o = 0; o < 4; ++o) Ao[o] *= inv;
+    Z += Zb;
+    float z[4];
+    quad_neighbour_order(z, Z, lane);
+    clip_softmax(Ao, z, g, scale);
 }
 
 // Stage one sample's word-side operands in slot order.  All global loads of the pass are issued before the first LDS store
@@ -322,7 +414,7 @@ static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + 
 // per 16-feature block and stops hipcc from scheduling across the blocks.
 // ROWS: 0 none, 1 fp32 rows, 2 rows stored as bf16 (round to nearest even; cchat then points to 16-bit elements)
 template <int DL, int WS, int ROWS, bool MEAN>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 3)
 void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                              const float* __restrict__ shat, const float* __restrict__ qmask,
@@ -456,7 +548,7 @@ __device__ __forceinline__ RowGeom row_geom16_nm(int n0, int n_end, int C, int l
 // b value the lane already holds (the 32x32x2 MFMA of the first version spent 12 of its 32 columns on padding), with more
 // words a second column block.  HOOK(t) is called once per step t = 0 .. 15: the next round's row loads are spread over the loop.
 template <int KIND, int DL, int WS, class HOOK>
-__device__ __forceinline__ void reduce_round(f32x4v (&rA)[2][2], float (&rE)[2][4], float (&cs)[2], float& csa, float& csb, float (&csx)[4],
+__device__ __forceinline__ void reduce_round(f32x4v (&rA)[2][2], f32x4v (&rE)[2], float (&cs)[2], float& csa, float& csb, float& csx,
                                              const float* T, const float* X, int fq, int lane, HOOK hook)
 {
     constexpr int LDA = DL + 4, LDP = bwd_ldp<WS>(), NB1 = WS - 4;
@@ -479,10 +571,12 @@ __device__ __forceinline__ void reduce_round(f32x4v (&rA)[2][2], float (&rE)[2][
             if (KIND == 0) csb += a1;
         }
         if (XV) {
-            const float4 pv = ldg4(Tr + 4 * t * LDP + 16);
-            rE[0][0] = fmaf(pv.x, x0, rE[0][0]); rE[0][1] = fmaf(pv.y, x0, rE[0][1]); rE[0][2] = fmaf(pv.z, x0, rE[0][2]); rE[0][3] = fmaf(pv.w, x0, rE[0][3]);
-            rE[1][0] = fmaf(pv.x, x1, rE[1][0]); rE[1][1] = fmaf(pv.y, x1, rE[1][1]); rE[1][2] = fmaf(pv.z, x1, rE[1][2]); rE[1][3] = fmaf(pv.w, x1, rE[1][3]);
-            if (KIND == 0) { csx[0] += pv.x; csx[1] += pv.y; csx[2] += pv.z; csx[3] += pv.w; }
+            // the four extra columns as 4 x 4 outer products: a block of the 4x4x1 MFMA is four adjacent features of one row, its a
+            // operand the row's extra-column values (lane & 3 picks the column): register i of lane (feature, kg) = column 16 + i
+            const float e = Tr[4 * t * LDP + 16 + (lane & 3)];
+            rE[0] = mfma4(e, x0, rE[0]);
+            rE[1] = mfma4(e, x1, rE[1]);
+            if (KIND == 0) csx += e;                                // lane (.., c): column 16 + c
         }
         if (KIND == 1) { cs[0] += x0; cs[1] += x1; } else csa += a0;
         if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -530,8 +624,8 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
         stage_vectors<DL, 256>(sS, sU, sQ, shat, uq, qmask, b, dl, Nq, tid);
         __syncthreads();
         // accumulators of the segment, [kind][column block][feature block]; rE: the four extra columns; cs*: column sums
-        f32x4v rA0[2][2], rA1[2][2];
-        float rE0[2][4], rE1[2][4], cs1[2] = {0.f, 0.f}, cs0a = 0.f, cs0b = 0.f, cs0x[4] = {0.f, 0.f, 0.f, 0.f}, csdummy[2] = {0.f, 0.f};
+        f32x4v rA0[2][2], rA1[2][2], rE0[2], rE1[2];
+        float cs1[2] = {0.f, 0.f}, cs0a = 0.f, cs0b = 0.f, cs0x = 0.f, csdummy[2] = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -566,33 +660,28 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 STAMP(1);
                 __syncthreads();                                    // the previous round's R0 is done with X / tDs (first writes below)
                 STAMP(2);
-                clip_attention16<DL>(Ao, ch, sS, g, scale, lane, [&](int j) {
-                    f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4v acc = words_tile16_S<LDM, WS>(z4, j, P, sW, lane);
-                    stg4(myX + 16 * j + 4 * kg, make_float4(acc[0], acc[1], acc[2], acc[3]));      // parked for the dq pass
-                    return acc;
-                });
+                clip_attention16_bwd<DL, WS>(Ao, ch, P, sW, sS, myX, g, scale, lane);      // a rows parked in X for the dq pass
 
                 STAMP(3);
                 // cchat = A chat :  dA[c][c^o] = <g_c, chat_{c^o}> ,  dchat_c = sum_o A[c^o][c] g_{c^o}
                 float dch[KJ][4];
-                float dAo[4] = {0.f, 0.f, 0.f, 0.f};
+                float dAo[4];
+                f32x4v dA4 = {0.f, 0.f, 0.f, 0.f}, dA4b = {0.f, 0.f, 0.f, 0.f};
                 const float An1 = nb<1>(Ao[1]), An2 = nb<2>(Ao[2]), An3 = nb<3>(Ao[3]);
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
-                    // effective output-gradient rows (both consumers summed, masked); the rows were requested a phase ago
-                    const bool dok = g.ok && 16 * j + 4 * kg < dl;
-                    const float gs = dok ? gscale : 0.f, ms = dok ? mscale : 0.f;
-                    float gvj[4] = {gq[j].x * gs, gq[j].y * gs, gq[j].z * gs, gq[j].w * gs};
-                    if (MEAN2) {
-                        gvj[0] = fmaf(gm[j].x, ms, gvj[0]); gvj[1] = fmaf(gm[j].y, ms, gvj[1]);
-                        gvj[2] = fmaf(gm[j].z, ms, gvj[2]); gvj[3] = fmaf(gm[j].w, ms, gvj[3]);
+                    // effective output-gradient rows (both consumers summed).  Rows of padding lanes and blocks past dl hold finite
+                    // values of other rows (clamped loads): they meet chat = 0, attention weights 0 or are never stored
+                    float gvj[4] = {gq[j].x, gq[j].y, gq[j].z, gq[j].w};
+                    if (PERCELL) { gvj[0] *= gscale; gvj[1] *= gscale; gvj[2] *= gscale; gvj[3] *= gscale; }      // rows: gscale = 1
+                    if (MEAN2) {                                    // the per-cell gradient arrives last (requested in R0)
+                        gvj[0] = fmaf(gm[j].x, mscale, gvj[0]); gvj[1] = fmaf(gm[j].y, mscale, gvj[1]);
+                        gvj[2] = fmaf(gm[j].z, mscale, gvj[2]); gvj[3] = fmaf(gm[j].w, mscale, gvj[3]);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float x = ch[j][q], y = gvj[q];
-                        dAo[0] = fmaf(y, x, dAo[0]);
-                        fmac_nb3(dAo[1], dAo[2], dAo[3], x, y, y, y);
+                        if (j & 1) dA4b = mfma4(x, y, dA4b); else dA4 = mfma4(x, y, dA4);      // register i: <chat_i, g_c> = dA[c][i]
                         dch[j][q] = Ao[0] * y;
                         fmac_nb_sum(dch[j][q], y, An1, An2, An3);
                     }
@@ -604,6 +693,8 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 float sym[4];
                 {
                     float rd = 0.f, dZ[4];
+                    dA4 += dA4b;
+                    quad_neighbour_order(dAo, dA4, lane);
 #pragma unroll
                     for (int o = 0; o < 4; ++o) { dAo[o] = kg_sum(dAo[o]); rd = fmaf(Ao[o], dAo[o], rd); }
 #pragma unroll
@@ -615,18 +706,16 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 }
                 // per 16-feature block: a (back from X) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
                 //                       -> da into X and straight into  dP^T[slot][n] += sum_d what[slot][d] da^T[d][n]  (MFMA)
-                f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f};
+                f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f}, dP0b = {0.f, 0.f, 0.f, 0.f}, dP1b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     const int d = 16 * j + 4 * kg;
-                    const float4 a4 = ldg4(myX + d);
+                    const float4 a4 = ldg4(myX + d);                 // a + shat (clip_attention16_bwd)
                     const float av4[4] = {a4.x, a4.y, a4.z, a4.w};
-                    const float4 sh = ldg4(sS + d);
-                    const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
                     float da4[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float tq = av4[q] + shv[q];
+                        const float tq = av4[q];
                         const float qv = ch[j][q] * tq;
                         float dq = sym[0] * qv;
                         fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
@@ -635,14 +724,15 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                     }
                     stg4(myX + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
                     const float4 w0 = ldg4(sW + l15 * LDM + d);
-                    dP0 = mfma16(w0.x, da4[0], dP0); dP0 = mfma16(w0.y, da4[1], dP0); dP0 = mfma16(w0.z, da4[2], dP0); dP0 = mfma16(w0.w, da4[3], dP0);
-                    if (WS == 5) dP1 = extra_words_partial<DL>(dP1, j, da4, sW, lane);
+                    dP0 = mfma16(w0.x, da4[0], dP0); dP0b = mfma16(w0.y, da4[1], dP0b); dP0 = mfma16(w0.z, da4[2], dP0); dP0b = mfma16(w0.w, da4[3], dP0b);
+                    if (WS == 5) { if (j & 1) dP1b = extra_words_partial<DL>(dP1b, j, da4, sW, lane); else dP1 = extra_words_partial<DL>(dP1, j, da4, sW, lane); }
                     else if (WS > 4) {
                         const float4 w1 = ldg4(sW + (16 + l15) * LDM + d);
                         dP1 = mfma16(w1.x, da4[0], dP1); dP1 = mfma16(w1.y, da4[1], dP1); dP1 = mfma16(w1.z, da4[2], dP1); dP1 = mfma16(w1.w, da4[3], dP1);
                     }
                     if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
+                dP0 += dP0b; dP1 += dP1b;
                 if (WS == 5) { const float d1 = extra_words_select(dP1, kg); dP1[0] = d1; dP1[1] = 0.f; dP1[2] = 0.f; dP1[3] = 0.f; }
                 STAMP(5);
                 // P = softmax(S), S = (raw + u) * scale * qmask
@@ -673,33 +763,51 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 STAMP(6);
                 // raw = chat Mq^T :  dchat^T[d][n] += sum_slots Mq[slot][d] dS^T[slot][n]   -> dchat = (...) * m   (chat = linear(fc) * m)
                 const float gm_ = g.m;
+                if constexpr (KJ >= 2) {
+                    float wa[2][WS], wb[2][WS];
+                    words_pair_load<LDM, WS>(wa[0], wb[0], 0, sM, lane);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    f32x4v acc = {dch[j][0], dch[j][1], dch[j][2], dch[j][3]};
-                    acc = words_tile16_S<LDM, WS>(acc, j, dS, sM, lane);
-                    const int d = 16 * j + 4 * kg;
+                    for (int jp = 0; jp < KJ / 2; ++jp) {
+                        const int cur = jp & 1;
+                        words_pair_pin<WS>(wa[cur], wb[cur]);
+                        f32x4v acc[2] = {{dch[2 * jp][0], dch[2 * jp][1], dch[2 * jp][2], dch[2 * jp][3]},
+                                         {dch[2 * jp + 1][0], dch[2 * jp + 1][1], dch[2 * jp + 1][2], dch[2 * jp + 1][3]}};
+                        words_pair_mfma<WS>(acc[0], acc[1], wa[cur], wb[cur], dS);
+                        if (jp + 1 < KJ / 2) words_pair_load<LDM, WS>(wa[cur ^ 1], wb[cur ^ 1], 2 * jp + 2, sM, lane);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int d = 16 * (2 * jp + u) + 4 * kg;
+                            if (g.ok && 16 * (2 * jp + u) < dl)
+                                stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[u][0] * gm_, acc[u][1] * gm_, acc[u][2] * gm_, acc[u][3] * gm_));
+                        }
+                    }
+                } else {
+                    f32x4v acc = {dch[0][0], dch[0][1], dch[0][2], dch[0][3]};
+                    acc = words_tile16_S<LDM, WS>(acc, 0, dS, sM, lane);
+                    const int d = 4 * kg;
                     if (g.ok && d < dl) stg4(dchat + (size_t)g.row * dl + d, make_float4(acc[0] * gm_, acc[1] * gm_, acc[2] * gm_, acc[3] * gm_));
-                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             STAMP(7);
             // next round's rows (past the segment: clamped to its last row, never used): requested inside the reduction loops below
             g = row_geom16_nm(c0 + 16 + 4 * wave, seg_end, C, lane, cellc);
-            const float* nx_chat = chat + (size_t)g.row * dl;
-            const float* nx_g = dcchat + (size_t)(PERCELL ? g.row / C : g.row) * dl;
-            const float* nx_m = dmean2 + (size_t)(g.row / C) * dl;
+            const float* nx_chat = chat + (size_t)g.row * dl + 4 * kg;
+            const float* nx_g = dcchat + (size_t)(PERCELL ? g.row / C : g.row) * dl + 4 * kg;
+            const float* nx_m = dmean2 + (size_t)(g.row / C) * dl + 4 * kg;
             STAMP(8);
             __syncthreads();                                        // the round's da / dS / P rows are in LDS
             STAMP(9);
             if (fq < DT) {                                          // R1: dwhat += P^T da, dshat += colsum da; the chat rows of the next round
-                float dcsa = 0.f, dcsb = 0.f, dcsx[4] = {0.f, 0.f, 0.f, 0.f};
+                float dcsa = 0.f, dcsb = 0.f, dcsx = 0.f;
                 reduce_round<1, DL, WS>(rA1, rE1, cs1, dcsa, dcsb, dcsx, tP, X, fq, lane, [&](int t) {
                     if (t == 0) mraw = cells[4 * (size_t)cellc + 3];
-                    if ((t & 1) == 0 && t / 2 < KJ) raw[t / 2] = ldg4(nx_chat + min(16 * (t / 2) + 4 * kg, dl - 4));
+                    if ((t & 1) == 0 && t / 2 < KJ) raw[t / 2] = ldg4(nx_chat + min(16 * (t / 2), dl - 16));
+                    if ((t & 1) == 1 && t / 2 < KJ) gq[t / 2] = ldg4(nx_g + min(16 * (t / 2), dl - 16));
                 });
             } else {
                 mraw = cells[4 * (size_t)cellc + 3];
                 fetch_rows16<DL>(raw, chat, g.row, dl, kg);
+                fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
             }
             STAMP(10);
             __syncthreads();                                        // every wave is done with the da rows
@@ -711,13 +819,9 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
             STAMP(13);
             if (fq < DT) {                                          // R0: dMq += dS^T chat, duq += colsum dS; the gradient rows of the next round
                 reduce_round<0, DL, WS>(rA0, rE0, csdummy, cs0a, cs0b, cs0x, tDs, X, fq, lane, [&](int t) {
-                    if ((t & 1) == 0 && t / 2 < KJ) gq[t / 2] = ldg4(nx_g + min(16 * (t / 2) + 4 * kg, dl - 4));
-                    if (MEAN2 && (t & 1) == 1 && t / 2 < KJ) gm[t / 2] = ldg4(nx_m + min(16 * (t / 2) + 4 * kg, dl - 4));
+                    if (MEAN2 && (t & 1) == 0 && t / 2 < KJ) gm[t / 2] = ldg4(nx_m + min(16 * (t / 2), dl - 16));
                 });
-            } else {
-                fetch_rows16<DL>(gq, dcchat, PERCELL ? g.row / C : g.row, dl, kg);
-                if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
-            }
+            } else if (MEAN2) fetch_rows16<DL>(gm, dmean2, g.row / C, dl, kg);
             STAMP(14);
         }
         // the segment's partial result: slab rows are tile columns (content_attn_reduce_kernel maps them to words)
@@ -748,14 +852,11 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 if (fok && kg == 0) sl[(size_t)64 * dl + feat] = c1;
             }
             // duq: column sums of dS (every wave holds the same sums: wave 0 writes)
-            const float ca = kg_sum(cs0a), cb = kg_sum(cs0b);
-            float cx[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cx[r] = kg_sum(cs0x[r]);
+            const float ca = kg_sum(cs0a), cb = kg_sum(cs0b), cx = kg_sum(cs0x);
             if (fq == 0 && kg == 0) {
                 sl[(size_t)64 * dl + dl + l15] = ca;
                 if (TWO) sl[(size_t)64 * dl + dl + 16 + l15] = cb;
-                if (XV && l15 < 4) sl[(size_t)64 * dl + dl + 16 + l15] = l15 == 0 ? cx[0] : (l15 == 1 ? cx[1] : (l15 == 2 ? cx[2] : cx[3]));
+                if (XV && l15 < 4) sl[(size_t)64 * dl + dl + 16 + l15] = cx;      // lanes 0 .. 3: columns 16 .. 19
             }
         }
         n = seg_end;
@@ -812,7 +913,7 @@ static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int*
                  float* cc_rows, float* cc_mean, int dl, int Nq, bool rows_bf16)
 {
     (void)B;
-    const int cpr = range_cells(N, 2 * attn_num_cus(), 16);      // two 256-thread workgroups per CU (203 registers)
+    const int cpr = range_cells(N, 3 * attn_num_cus(), 16);      // three 256-thread workgroups per CU (<= 168 registers, 36 KB of LDS each)
     const dim3 grid(cdiv(N, cpr));
     const size_t lds = fwd_lds_bytes<DL>();
     const float scale = 1.0f / sqrtf((float)dl);
@@ -928,7 +1029,7 @@ extern "C" int smin_content_attn_fwd(void* stream, const float* chat, const int3
                                      const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                                      float* cc, float* ccmean)
 {
-    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    SMIN_REQUIRE(dl % 16 == 0 && dl >= 16 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     SMIN_REQUIRE(cc || ccmean);
     ProfScope prof((hipStream_t)stream, SMIN_PROF_ATTN_FWD);
@@ -940,7 +1041,7 @@ extern "C" int smin_content_attn_fwd_cch(void* stream, const float* chat, const 
                                          const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                                          uint16_t* cc_h, float* ccmean)
 {
-    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    SMIN_REQUIRE(dl % 16 == 0 && dl >= 16 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     SMIN_REQUIRE(cc_h && ccmean);
     return launch_content_attn_fwd_h((hipStream_t)stream, chat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, cc_h, ccmean, dl, Nq);
@@ -968,7 +1069,7 @@ extern "C" int smin_content_attn_bwd(void* stream, const float* dcc, const float
                                      float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
-    SMIN_REQUIRE(dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    SMIN_REQUIRE(dl % 16 == 0 && dl >= 16 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     SMIN_REQUIRE(dcc || dccmean);
     SMIN_REQUIRE(ws_bytes >= smin_content_attn_bwd_workspace_bytes(N, B, C, dl));

@@ -148,7 +148,7 @@ extern "C" int smin_content_unit_fwd(void* stream, const float* fc, const float*
                                      float* fc_out, float* fcmean, float* chat, float* cchat)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    SMIN_REQUIRE(D % 4 == 0 && dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    SMIN_REQUIRE(D % 4 == 0 && dl % 16 == 0 && dl >= 16 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     const int M = N * C;
     int rc = launch_gemm_nt(st, PlainMat{fc, D}, PlainMat{Wch, D}, EpBiasMask{bch, cells, chat, C}, M, dl, D);
@@ -241,7 +241,7 @@ extern "C" int smin_content_unit_bwd(void* stream, const float* dfc_out, const f
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     SMIN_REQUIRE(!(last && dfc_out));                           // "last" means nothing consumed fc_out itself
-    SMIN_REQUIRE(D % 4 == 0 && dl % 8 == 0 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
+    SMIN_REQUIRE(D % 4 == 0 && dl % 16 == 0 && dl >= 16 && dl <= 128 && C >= 2 && C <= 4 && Nq >= 1 && Nq <= 32);
     if (N == 0) return 0;
     if (dfc_out)
         return content_unit_bwd_impl<true>(st, dfc_out, dfcmean, fc, cells, row_ptr, N, B, L, C, D, dl, Nq, WchT, Mq, uq, what, shat, qmask,
