@@ -76,6 +76,12 @@ struct RowGeom {
 // and the P / dS accumulators feed the next MFMA as B operands without any data movement.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// exp and reciprocal of the two softmaxes as single instructions (v_exp_f32 after a multiply by log2 e; v_rcp_f32): 1 ulp each,
+// against ~14 instructions per expf and ~10 per IEEE division -- 12 exponentials and 2 divisions per backward tile.  The arguments
+// are differences to the row maximum (<= 0; -inf for masked entries gives exactly 0).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products, block b = lanes 4b .. 4b+3: lane 4b + j, register i gets
 // a[lane 4b + i] * b[lane 4b + j] (layout confirmed on gfx950 by tools/mfma4x4_probe.hip).  Two passes (8 cycles): a quarter of a
 // 16x16x4 step for the same FLOPs, all of them useful when only four words are contracted.
@@ -131,12 +137,15 @@ __device__ __forceinline__ void mask_rows16(float (&v)[DL / 16][4], const float4
 // lane group contracts its own features; kg_sum adds the four partial sums.  32 two-pass MFMAs instead of 32 eight-pass ones
 // of which 12 of 16 output rows were padding.
 template <int DL>
-__device__ __forceinline__ f32x4v extra_words_partial(f32x4v acc, int j, const float (&v)[4], const float* sX, int lane)
+__device__ __forceinline__ float4 extra_words_operand(int j, const float* sX, int lane)
 {
     constexpr int LDM = DL + 4;
-    const float4 a = ldg4(sX + (16 + 4 * (lane & 3)) * LDM + 16 * j + 4 * (lane >> 4));
-    acc = mfma4(a.x, v[0], acc); acc = mfma4(a.y, v[1], acc); acc = mfma4(a.z, v[2], acc); acc = mfma4(a.w, v[3], acc);
-    return acc;
+    return ldg4(sX + (16 + 4 * (lane & 3)) * LDM + 16 * j + 4 * (lane >> 4));
+}
+// two accumulators, alternating: consecutive MFMAs are independent
+__device__ __forceinline__ void extra_words_mfma(f32x4v& accA, f32x4v& accB, float4 a, const float (&v)[4])
+{
+    accA = mfma4(a.x, v[0], accA); accB = mfma4(a.y, v[1], accB); accA = mfma4(a.z, v[2], accA); accB = mfma4(a.w, v[3], accB);
 }
 // every lane: the four totals; lane group kg keeps word 16 + kg (its slot 16 + 4 kg + 0)
 __device__ __forceinline__ float extra_words_select(f32x4v acc, int kg)
@@ -153,26 +162,52 @@ template <int DL, int WS>
 __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch)[DL / 16][4], const float* sM, const float* sU, const float* sQ,
                                                  int Nq, float scale, int lane)
 {
-    constexpr int LDM = DL + 4;
+    constexpr int LDM = DL + 4, KJ = DL / 16, G = KJ >= 2 ? 2 : 1, NG = KJ / G;
+    constexpr int NR = WS >= 8 ? 8 : WS;                          // score registers that can hold a word: slots 16 + 4kg + r, r < WS - 4
     const int l15 = lane & 15, kg = lane >> 4;
     // two accumulators per block, alternating: a dependent 16x16x4 MFMA issues 40 cycles after its predecessor, an independent one 32
     f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S0b = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f}, S1b = {0.f, 0.f, 0.f, 0.f};
+    // word operands in batches of G blocks, requested one batch ahead and pinned (one wait per batch; left alone hipcc emits
+    // read -> wait -> 4 MFMAs for every block and every block pays the LDS latency)
+    float4 a0[2][G], a1[2][G];
+    auto request = [&](int gI, int buf) {
 #pragma unroll
-    for (int j = 0; j < DL / 16; ++j) {
-        const float4 a0 = ldg4(sM + l15 * LDM + 16 * j + 4 * kg);
-        S0 = mfma16(a0.x, ch[j][0], S0); S0b = mfma16(a0.y, ch[j][1], S0b); S0 = mfma16(a0.z, ch[j][2], S0); S0b = mfma16(a0.w, ch[j][3], S0b);
-        if (WS == 5) { if (j & 1) S1b = extra_words_partial<DL>(S1b, j, ch[j], sM, lane); else S1 = extra_words_partial<DL>(S1, j, ch[j], sM, lane); }
-        else if (WS > 4) {
-            const float4 a1 = ldg4(sM + (16 + l15) * LDM + 16 * j + 4 * kg);
-            S1 = mfma16(a1.x, ch[j][0], S1); S1 = mfma16(a1.y, ch[j][1], S1); S1 = mfma16(a1.z, ch[j][2], S1); S1 = mfma16(a1.w, ch[j][3], S1);
+        for (int u = 0; u < G; ++u) {
+            const int j = G * gI + u;
+            a0[buf][u] = ldg4(sM + l15 * LDM + 16 * j + 4 * kg);
+            if (WS == 5) a1[buf][u] = extra_words_operand<DL>(j, sM, lane);
+            else if (WS > 4) a1[buf][u] = ldg4(sM + (16 + l15) * LDM + 16 * j + 4 * kg);
         }
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    };
+    request(0, 0);
+#pragma unroll
+    for (int gI = 0; gI < NG; ++gI) {
+        const int buf = gI & 1;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            asm volatile("" : "+v"(a0[buf][u].x), "+v"(a0[buf][u].y), "+v"(a0[buf][u].z), "+v"(a0[buf][u].w));
+            if (WS > 4) asm volatile("" : "+v"(a1[buf][u].x), "+v"(a1[buf][u].y), "+v"(a1[buf][u].z), "+v"(a1[buf][u].w));
+        }
+        if (gI + 1 < NG) request(gI + 1, buf ^ 1);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int j = G * gI + u;
+            const float4 x = a0[buf][u];
+            S0 = mfma16(x.x, ch[j][0], S0); S0b = mfma16(x.y, ch[j][1], S0b); S0 = mfma16(x.z, ch[j][2], S0); S0b = mfma16(x.w, ch[j][3], S0b);
+            if (WS == 5) extra_words_mfma(S1, S1b, a1[buf][u], ch[j]);
+            else if (WS > 4) {
+                const float4 y = a1[buf][u];
+                S1 = mfma16(y.x, ch[j][0], S1); S1b = mfma16(y.y, ch[j][1], S1b); S1 = mfma16(y.z, ch[j][2], S1); S1b = mfma16(y.w, ch[j][3], S1b);
+            }
+        }
     }
     S0 += S0b; S1 += S1b;
     if (WS == 5) { const float s1 = extra_words_select(S1, kg); S1[0] = s1; S1[1] = 0.f; S1[2] = 0.f; S1[3] = 0.f; }      // slots 16 + 4kg + r, r > 0: words >= 20
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 8; ++r) P[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         const int sl = 16 * (r >> 2) + 4 * kg + (r & 3);          // slot; its word is 16b + 4r + kg
         const int w = 16 * (r >> 2) + 4 * (r & 3) + kg;
         float v = ((r < 4 ? S0[r & 3] : S1[r & 3]) + sU[sl]) * scale;
@@ -185,11 +220,11 @@ __device__ __forceinline__ void scores_softmax16(float (&P)[8], const float (&ch
     mx = kg_max(mx);
     float den = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { P[r] = expf(P[r] - mx); den += P[r]; }
+    for (int r = 0; r < NR; ++r) { P[r] = fast_exp(P[r] - mx); den += P[r]; }
     den = kg_sum(den);
-    const float inv = 1.0f / den;
+    const float inv = fast_rcp(den);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) P[r] *= inv;
+    for (int r = 0; r < NR; ++r) P[r] *= inv;
 }
 
 // out^T block j: acc[r] += sum_slots X[slot][16j + 4kg' ...]: the contraction over words with the word operand read from the
@@ -272,8 +307,8 @@ __device__ __forceinline__ void clip_softmax(float (&Ao)[4], float (&z)[4], cons
     }
     float den = 0.f;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { Ao[o] = expf(z[o] - mx); den += Ao[o]; }
-    const float inv = g.m / den;                                  // models.py:262-263: softmax, then * mask
+    for (int o = 0; o < 4; ++o) { Ao[o] = fast_exp(z[o] - mx); den += Ao[o]; }
+    const float inv = g.m * fast_rcp(den);                        // models.py:262-263: softmax, then * mask
 #pragma unroll
     for (int o = 0; o < 4; ++o) Ao[o] *= inv;
 }
@@ -707,30 +742,44 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
                 // per 16-feature block: a (back from X) -> q = chat*(a+shat) -> dq = sum_o sym[o] q_{c^o} -> dchat += dq (a+shat), da = dq chat
                 //                       -> da into X and straight into  dP^T[slot][n] += sum_d what[slot][d] da^T[d][n]  (MFMA)
                 f32x4v dP0 = {0.f, 0.f, 0.f, 0.f}, dP1 = {0.f, 0.f, 0.f, 0.f}, dP0b = {0.f, 0.f, 0.f, 0.f}, dP1b = {0.f, 0.f, 0.f, 0.f};
+                {
+                    // LDS operands of block j + 1 are requested before block j's arithmetic and pinned before their use (one wait)
+                    float4 a4b[2], w0b[2], w1b[2];
+                    auto request = [&](int j, int buf) {
+                        const int d = 16 * j + 4 * kg;
+                        a4b[buf] = ldg4(myX + d);                    // a + shat (clip_attention16_bwd)
+                        w0b[buf] = ldg4(sW + l15 * LDM + d);
+                        if (WS == 5) w1b[buf] = extra_words_operand<DL>(j, sW, lane);
+                        else if (WS > 4) w1b[buf] = ldg4(sW + (16 + l15) * LDM + d);
+                    };
+                    request(0, 0);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    const int d = 16 * j + 4 * kg;
-                    const float4 a4 = ldg4(myX + d);                 // a + shat (clip_attention16_bwd)
-                    const float av4[4] = {a4.x, a4.y, a4.z, a4.w};
-                    float da4[4];
+                    for (int j = 0; j < KJ; ++j) {
+                        const int buf = j & 1, d = 16 * j + 4 * kg;
+                        asm volatile("" : "+v"(a4b[buf].x), "+v"(a4b[buf].y), "+v"(a4b[buf].z), "+v"(a4b[buf].w));
+                        asm volatile("" : "+v"(w0b[buf].x), "+v"(w0b[buf].y), "+v"(w0b[buf].z), "+v"(w0b[buf].w));
+                        if (WS > 4) asm volatile("" : "+v"(w1b[buf].x), "+v"(w1b[buf].y), "+v"(w1b[buf].z), "+v"(w1b[buf].w));
+                        if (j + 1 < KJ) request(j + 1, buf ^ 1);
+                        const float av4[4] = {a4b[buf].x, a4b[buf].y, a4b[buf].z, a4b[buf].w};
+                        float da4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float tq = av4[q];
-                        const float qv = ch[j][q] * tq;
-                        float dq = sym[0] * qv;
-                        fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
-                        dch[j][q] = fmaf(dq, tq, dch[j][q]);
-                        da4[q] = dq * ch[j][q];                     // 0 on padding lanes and past dl (ch is 0 there)
+                        for (int q = 0; q < 4; ++q) {
+                            const float tq = av4[q];
+                            const float qv = ch[j][q] * tq;
+                            float dq = sym[0] * qv;
+                            fmac_nb_sum(dq, qv, sym[1], sym[2], sym[3]);
+                            dch[j][q] = fmaf(dq, tq, dch[j][q]);
+                            da4[q] = dq * ch[j][q];                 // 0 on padding lanes and past dl (ch is 0 there)
+                        }
+                        stg4(myX + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
+                        const float4 w0 = w0b[buf];
+                        dP0 = mfma16(w0.x, da4[0], dP0); dP0b = mfma16(w0.y, da4[1], dP0b); dP0 = mfma16(w0.z, da4[2], dP0); dP0b = mfma16(w0.w, da4[3], dP0b);
+                        if (WS == 5) extra_words_mfma(dP1, dP1b, w1b[buf], da4);
+                        else if (WS > 4) {
+                            const float4 w1 = w1b[buf];
+                            dP1 = mfma16(w1.x, da4[0], dP1); dP1b = mfma16(w1.y, da4[1], dP1b); dP1 = mfma16(w1.z, da4[2], dP1); dP1b = mfma16(w1.w, da4[3], dP1b);
+                        }
                     }
-                    stg4(myX + d, make_float4(da4[0], da4[1], da4[2], da4[3]));
-                    const float4 w0 = ldg4(sW + l15 * LDM + d);
-                    dP0 = mfma16(w0.x, da4[0], dP0); dP0b = mfma16(w0.y, da4[1], dP0b); dP0 = mfma16(w0.z, da4[2], dP0); dP0b = mfma16(w0.w, da4[3], dP0b);
-                    if (WS == 5) { if (j & 1) dP1b = extra_words_partial<DL>(dP1b, j, da4, sW, lane); else dP1 = extra_words_partial<DL>(dP1, j, da4, sW, lane); }
-                    else if (WS > 4) {
-                        const float4 w1 = ldg4(sW + (16 + l15) * LDM + d);
-                        dP1 = mfma16(w1.x, da4[0], dP1); dP1 = mfma16(w1.y, da4[1], dP1); dP1 = mfma16(w1.z, da4[2], dP1); dP1 = mfma16(w1.w, da4[3], dP1);
-                    }
-                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 dP0 += dP0b; dP1 += dP1b;
                 if (WS == 5) { const float d1 = extra_words_select(dP1, kg); dP1[0] = d1; dP1[1] = 0.f; dP1[2] = 0.f; dP1[3] = 0.f; }
