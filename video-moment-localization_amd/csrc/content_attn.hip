@@ -448,7 +448,9 @@ static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + 
 // ROWS / MEAN: which outputs exist.  Compile-time: a runtime `if (pointer)` inside the unrolled output loop costs a branch
 // per 16-feature block and stops hipcc from scheduling across the blocks.
 // ROWS: 0 none, 1 fp32 rows, 2 rows stored as bf16 (round to nearest even; cchat then points to 16-bit elements)
-template <int DL, int WS, int ROWS, bool MEAN>
+// EXACT: dl == DL and C == 4 (every shipped configuration): row strides, feature clamps and clip predicates are constants --
+// fewer address instructions and far fewer scalar registers (the general form keeps a clamped offset and a predicate per block)
+template <int DL, int WS, int ROWS, bool MEAN, bool EXACT>
 __global__ __launch_bounds__(256, 3)
 void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
@@ -457,6 +459,7 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int KJ = DL / 16;
+    if (EXACT) { dl = DL; C = 4; }
     float* sM = smem_dyn; float* sWT = sM + 32 * (DL + 4); float* sS = sWT + DL * LDW; float* sU = sS + DL; float* sQ = sU + 32;
     const int n_lo = blockIdx.x * cells_per_range;
     if (n_lo >= N) return;
@@ -618,7 +621,7 @@ __device__ __forceinline__ void reduce_round(f32x4v (&rA)[2][2], f32x4v (&rE)[2]
     }
 }
 
-template <int DL, int WS, bool MEAN2, bool PERCELL>
+template <int DL, int WS, bool MEAN2, bool PERCELL, bool EXACT>
 __global__ __launch_bounds__(256, 2)
 void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __restrict__ dcchat,
                              const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
@@ -631,6 +634,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     constexpr int LDM = DL + 4, KJ = DL / 16, LDA = DL + 4, DT = (DL + 31) / 32, LDP = bwd_ldp<WS>(), NB1 = WS - 4, NCOLS = bwd_ncols<WS>();
     constexpr bool TWO = NB1 >= 2, XV = NB1 == 1;
+    if (EXACT) { dl = DL; C = 4; }
     float* sM = smem_dyn; float* sW = sM + 32 * LDM; float* sS = sW + 32 * LDM; float* sU = sS + DL; float* sQ = sU + 32;
     float* X = sQ + 32; float* tDs = X + 64 * LDA; float* tP = tDs + 64 * LDP;
     const int rg = blockIdx.x;
@@ -956,7 +960,7 @@ static int range_cells(int N, int slots, int min_cells)
 }
 int content_attn_bwd_range_cells(int N) { return range_cells(N, 2 * attn_num_cus(), 16); }      // two 256-thread workgroups per CU, whole rounds
 
-template <int DL, int WS>
+template <int DL, int WS, bool EXACT>
 static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* cc_rows, float* cc_mean, int dl, int Nq, bool rows_bf16)
@@ -967,33 +971,40 @@ static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int*
     const size_t lds = fwd_lds_bytes<DL>();
     const float scale = 1.0f / sqrtf((float)dl);
     if (rows_bf16)                                                // (rows + mean: the only bf16-rows combination a host asks for)
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 2, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 2, true, EXACT>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     else if (cc_rows && cc_mean)
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, true, EXACT>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     else if (cc_rows)
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, false>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 1, false, EXACT>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     else
-        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 0, true>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
+        hipLaunchKernelGGL((content_attn_fwd_kernel<DL, WS, 0, true, EXACT>), grid, dim3(256), lds, st, chat, cells, row_ptr, L, C, Mq, uq, what, shat, qmask,
                            cc_rows, cc_mean, dl, Nq, N, cpr, scale);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
 
 // kernels exist for these (feature width, word steps) pairs: the production width 128 with 4 / 5 / 6 / 8 steps of four
-// words (Nq <= 16 / 20 / 24 / 32), narrower widths with 4 or 8
+// words (Nq <= 16 / 20 / 24 / 32), narrower widths with 4 or 8; shapes with dl below the width or fewer than four clips
+// run the general form at the widest word count
 #define SMIN_ATTN_DISPATCH(FN, ...)                                                                        \
     do {                                                                                                    \
         const int nws__ = (Nq + 3) / 4;                                                                      \
-        if (dl <= 16) return nws__ <= 4 ? FN<16, 4>(__VA_ARGS__) : FN<16, 8>(__VA_ARGS__);                     \
-        if (dl <= 32) return nws__ <= 4 ? FN<32, 4>(__VA_ARGS__) : FN<32, 8>(__VA_ARGS__);                     \
-        if (dl <= 64) return nws__ <= 4 ? FN<64, 4>(__VA_ARGS__) : FN<64, 8>(__VA_ARGS__);                     \
-        if (nws__ <= 4) return FN<128, 4>(__VA_ARGS__);                                                        \
-        if (nws__ == 5) return FN<128, 5>(__VA_ARGS__);                                                        \
-        if (nws__ == 6) return FN<128, 6>(__VA_ARGS__);                                                        \
-        return FN<128, 8>(__VA_ARGS__);                                                                     \
+        if (!(C == 4 && (dl == 16 || dl == 32 || dl == 64 || dl == 128))) {                                   \
+            if (dl <= 16) return FN<16, 8, false>(__VA_ARGS__);                                                \
+            if (dl <= 32) return FN<32, 8, false>(__VA_ARGS__);                                                \
+            if (dl <= 64) return FN<64, 8, false>(__VA_ARGS__);                                                \
+            return FN<128, 8, false>(__VA_ARGS__);                                                          \
+        }                                                                                                   \
+        if (dl == 16) return nws__ <= 4 ? FN<16, 4, true>(__VA_ARGS__) : FN<16, 8, true>(__VA_ARGS__);         \
+        if (dl == 32) return nws__ <= 4 ? FN<32, 4, true>(__VA_ARGS__) : FN<32, 8, true>(__VA_ARGS__);         \
+        if (dl == 64) return nws__ <= 4 ? FN<64, 4, true>(__VA_ARGS__) : FN<64, 8, true>(__VA_ARGS__);         \
+        if (nws__ <= 4) return FN<128, 4, true>(__VA_ARGS__);                                                  \
+        if (nws__ == 5) return FN<128, 5, true>(__VA_ARGS__);                                                  \
+        if (nws__ == 6) return FN<128, 6, true>(__VA_ARGS__);                                                  \
+        return FN<128, 8, true>(__VA_ARGS__);                                                               \
     } while (0)
 
 int launch_content_attn_fwd(hipStream_t st, const float* chat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
@@ -1021,7 +1032,7 @@ size_t content_attn_bwd_ws_floats(int N, int B, int dl)
     return ((size_t)cdiv(N > 0 ? N : 1, cpr) + B + 1) * ((size_t)64 * dl + dl + 32) + 64;
 }
 
-template <int DL, int WS, bool MEAN2, bool PERCELL>
+template <int DL, int WS, bool MEAN2, bool PERCELL, bool EXACT>
 static int bwd_v(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
@@ -1030,13 +1041,13 @@ static int bwd_v(hipStream_t st, const float* chat, const float* dcchat, const i
     const int cpr = content_attn_bwd_range_cells(N);
     static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL, EXACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(bwd_lds_bytes<DL, WS>()));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const size_t lds = bwd_lds_bytes<DL, WS>();
-    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL>), dim3(cdiv(N, cpr)), dim3(256), lds, st, chat, dcchat, cells, row_ptr, L, C,
+    hipLaunchKernelGGL((content_attn_bwd_kernel<DL, WS, MEAN2, PERCELL, EXACT>), dim3(cdiv(N, cpr)), dim3(256), lds, st, chat, dcchat, cells, row_ptr, L, C,
                        Mq, uq, what, shat, qmask, dchat, ws, dl, Nq, N, cpr, 1.0f / sqrtf((float)dl), g_per_cell, gscale, dmean2, mscale);
     SMIN_LAUNCH_CHECK();
     const int slab_sz = 64 * dl + dl + 32;
@@ -1045,17 +1056,17 @@ static int bwd_v(hipStream_t st, const float* chat, const float* dcchat, const i
     return 0;
 }
 
-template <int DL, int WS>
+template <int DL, int WS, bool EXACT>
 static int bwd_t(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
                  const float* Mq, const float* uq, const float* what, const float* shat, const float* qmask,
                  float* dchat, float* dMq, float* duq, float* dwhat, float* dshat, float* ws, int dl, int Nq, int g_per_cell, float gscale,
                  const float* dmean2, float mscale)
 {
     if (dmean2)
-        return bwd_v<DL, WS, true, false>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, dmean2, mscale);
+        return bwd_v<DL, WS, true, false, EXACT>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, dmean2, mscale);
     if (g_per_cell)
-        return bwd_v<DL, WS, false, true>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 1, gscale, nullptr, mscale);
-    return bwd_v<DL, WS, false, false>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, nullptr, mscale);
+        return bwd_v<DL, WS, false, true, EXACT>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 1, gscale, nullptr, mscale);
+    return bwd_v<DL, WS, false, false, EXACT>(st, chat, dcchat, cells, row_ptr, N, B, L, C, Mq, uq, what, shat, qmask, dchat, dMq, duq, dwhat, dshat, ws, dl, Nq, 0, gscale, nullptr, mscale);
 }
 
 int launch_content_attn_bwd(hipStream_t st, const float* chat, const float* dcchat, const int* cells, const int* row_ptr, int N, int B, int L, int C,
