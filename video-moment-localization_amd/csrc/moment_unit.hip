@@ -36,9 +36,14 @@ struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradi
 // One 128-thread workgroup per (b, l); gather only -> deterministic.
 __global__ __launch_bounds__(128)
 void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ fb, const int* __restrict__ cells,
-                       const int* __restrict__ row_ptr, const int* __restrict__ cellmap, int L, int D, float* __restrict__ dfb)
+                       const int* __restrict__ row_ptr, const int* __restrict__ cellmap, int B, int L, int D, float* __restrict__ dfb)
 {
-    const int l = blockIdx.x, b = blockIdx.y;
+    // every row of dX1 is read twice, by the workgroup of its start snippet and by that of its end snippet: all workgroups of a
+    // sample sit on ONE XCD (ids id and id + 8 share an XCD under round-robin placement: speed only), so that the second read is
+    // an L2 hit while the sample's 4 MB of dX1 pass through (dealt over all eight L2s the launch fetched 2.0x the tensor)
+    const int id = blockIdx.x, slot = id >> 3;
+    const int l = slot % L, b = (slot / L) * 8 + (id & 7);
+    if (b >= B) return;
     const float* fbb = fb + (size_t)b * L * D;
     const int r0 = row_ptr[b * L + l], r1 = row_ptr[b * L + l + 1];
     const int* cmap = cellmap + (size_t)b * L * L;
@@ -188,7 +193,7 @@ static int moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, 
         (void)hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
     }
     if (want_in) {
-        hipLaunchKernelGGL(moment_dfb_kernel, dim3(L, B), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, L, D, dfb);
+        hipLaunchKernelGGL(moment_dfb_kernel, dim3(L * 8 * cdiv(B, 8)), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, B, L, D, dfb);
         SMIN_LAUNCH_CHECK();
     }
     return 0;

@@ -253,13 +253,19 @@ __global__ __launch_bounds__(128)
 void proposal_map_bwd_events2_kernel(Src src, const float* __restrict__ dfm,
                                      const int* __restrict__ cells, const int* __restrict__ cellmap,
                                      const int* __restrict__ ev_off, const Ev* __restrict__ ev_tab,
-                                     int T, int L, int C, int D, float* __restrict__ E, int check_mask)
+                                     int B, int T, int L, int C, int D, float* __restrict__ E, int check_mask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Ev* list = reinterpret_cast<Ev*>(lds_raw);                      // [2][EV_CAP]
     int* wcnt = reinterpret_cast<int*>(list + 2 * EV_CAP);          // [2] events in each wave's list
     float4* red = reinterpret_cast<float4*>(lds_raw + 2 * EV_CAP * sizeof(Ev) + 16);   // [128][NS]
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // All frames of a sample on ONE XCD (workgroups id and id + 8 share an XCD under the observed round-robin placement: speed
+    // only): a clip's gradient row is read at its start frame and again at its end frame, by two workgroups of the same sample
+    // that are in flight together -- with (t, b) dealt over all eight L2s the second read went to the fabric (1.24 GB fetched for
+    // 0.62 GB of rows).
+    const int id = blockIdx.x, slot = id >> 3;
+    const int t = slot % T, b = (slot / T) * 8 + (id & 7), tid = threadIdx.x;
+    if (b >= B) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int* cmap = cellmap + (size_t)b * L * L;
     const float invC = 1.0f / C;
@@ -404,7 +410,8 @@ static int launch_events2_t(hipStream_t st, const Src& src, const float* dfm, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((proposal_map_bwd_events2_kernel<Src, NS, UNR, HAS_M>), dim3(T, B), dim3(128), lds, st, src, dfm, cells, cellmap, ev_off, ev_tab, T, L, C, D, E, 1);
+    hipLaunchKernelGGL((proposal_map_bwd_events2_kernel<Src, NS, UNR, HAS_M>), dim3(T * 8 * cdiv(B, 8)), dim3(128), lds, st, src, dfm, cells, cellmap, ev_off, ev_tab,
+                       B, T, L, C, D, E, 1);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
