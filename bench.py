@@ -22,7 +22,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see video-moment-localization_amd/__init__.py (read when the HIP runtime initialises)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -393,7 +395,9 @@ def main():
         exchange = ""
         if world_seen > 1 or backend is not None:
             lib_name = {"nccl": "RCCL (torch backend nccl)", "gloo": "gloo (host-staged; NOT RCCL)"}.get(backend, str(backend))
-            exchange = f"+gradient all-reduce (DDP) over {lib_name}, process group of {world_seen}"
+            how = {"in_node": "issued by the one-node backward as gradient groups become final, overlapped with it",
+                   "torch_ddp": "torch DistributedDataParallel buckets"}.get(getattr(model, "grad_exchange", None), "none")
+            exchange = f"+gradient all-reduce ({how}) over {lib_name}, process group of {world_seen}"
         out = {
             "metric": "proposals/sec (fwd+bwd)", "value": total_B * L * L / (elapsed / args.steps), "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_with_adam": None if args.no_optimizer else ms,
@@ -406,7 +410,7 @@ def main():
                                    + ("" if args.no_optimizer else "+Adam (torch fused)" if not os.environ.get("SMIN_FOREACH_ADAM") else "+Adam (torch foreach)") + exchange,
                        "global_batch": total_B, "valid_cells_per_step": n_valid_total,
                        "valid_cells_per_s": n_valid_total / (elapsed / args.steps), "parallelism": f"dp{world}", "dist_backend": backend, "dist_world_size": world_seen,
-                       "ddp_overrides": getattr(model, "ddp_overrides", None),
+                       "ddp_overrides": getattr(model, "ddp_overrides", None), "grad_exchange": getattr(model, "grad_exchange", None),
                        "final_loss": float(loss.item())},
             "roofline": roofline,
         }

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
+#include <ATen/core/dispatch/Dispatcher.h>
+#include <ATen/core/stack.h>
 
 #include <cmath>
 #include <map>
@@ -56,17 +58,24 @@ struct StreamScope {                       // torch's current stream for the sco
     ~StreamScope() { c10::hip::setCurrentHIPStream(prev); }
 };
 
+// Events for stream joins: a ring per device (an event is bound to the device it was created on), created under that device's
+// guard.  A draw is consumed (recorded and waited for by hipStreamWaitEvent, or synchronised by the host) within the call that
+// drew it; the ring is far longer than the draws of one forward + backward pass (~60 at three layers), so no event is
+// re-recorded while a wait on its previous record is still being enqueued.
 hipEvent_t next_event()
 {
+    constexpr size_t RING = 1024;
     static std::mutex mu;
-    static std::vector<hipEvent_t> ring;
-    static size_t pos = 0;
+    static std::map<int, std::pair<std::vector<hipEvent_t>, size_t>> rings;
+    int dev = 0;
+    TORCH_CHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
     std::lock_guard<std::mutex> lk(mu);
-    if (ring.empty()) {
-        ring.resize(256);
-        for (auto& e : ring) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    auto& ring = rings[dev];
+    if (ring.first.empty()) {
+        ring.first.resize(RING);
+        for (auto& e : ring.first) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
     }
-    return ring[pos++ % ring.size()];
+    return ring.first[ring.second++ % RING];
 }
 // `waiter` waits for everything queued on `on` so far (stream.wait_stream)
 void wait_stream(HStream waiter, HStream on)
@@ -147,6 +156,59 @@ std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, 
 }
 
 Tensor undef() { return Tensor(); }
+
+// ---------------------------------------------------------------- gradient exchange inside the node (data parallel)
+// With the whole model as one autograd node torch DDP sees every gradient only when the node returns: its all-reduce would start
+// after the backward pass.  Instead the node hands each group of finished gradient buffers to the process group itself
+// (c10d functional collectives, i.e. RCCL on a HIP device), on the stream that produced them, as soon as they are final -- the
+// boundary unit's and moment unit's weights layer by layer, the inputs of the parameter-product kernel before it runs (its outputs
+// are linear in them with coefficients that are equal on every rank, so they come out averaged), the word-side and localization
+// gradients behind their kernels, the backbone's at the end -- and the main stream joins the collectives before the node returns.
+struct GradSyncConfig { std::string group; int world = 1; bool coalesced_avg = false; };
+GradSyncConfig& grad_sync_config() { static GradSyncConfig c; return c; }
+
+struct GradSync {
+    bool on = false;
+    std::vector<Tensor> pending;
+    static c10::OperatorHandle op(const char* name) { return c10::Dispatcher::singleton().findSchemaOrThrow(name, ""); }
+    // every tensor: a contiguous gradient buffer, handed over exactly once; `on_stream` = the stream its producer ran on
+    void reduce(const std::vector<Tensor>& ts_in, HStream on_stream)
+    {
+        if (!on) return;
+        std::vector<Tensor> ts;
+        for (auto& t : ts_in) if (t.defined() && t.numel() > 0) { TORCH_CHECK(t.is_contiguous(), "grad sync: non-contiguous gradient buffer"); ts.push_back(t); }
+        if (ts.empty()) return;
+        const GradSyncConfig& c = grad_sync_config();
+        StreamScope sc(on_stream);
+        if (c.coalesced_avg) {                                   // RCCL: one grouped launch, averaged by the library
+            static auto h = op("_c10d_functional::all_reduce_coalesced_");
+            torch::jit::Stack stack;
+            stack.emplace_back(ts); stack.emplace_back(std::string("avg")); stack.emplace_back(c.group);
+            h.callBoxed(stack);
+            for (auto& t : ts) pending.push_back(t);
+        } else {                                                  // gloo (tests): per tensor, summed, then scaled
+            static auto h = op("_c10d_functional::all_reduce_");
+            static auto w = op("_c10d_functional::wait_tensor");
+            for (auto& t : ts) {
+                torch::jit::Stack stack;
+                stack.emplace_back(t); stack.emplace_back(std::string("sum")); stack.emplace_back(c.group);
+                h.callBoxed(stack);
+                torch::jit::Stack ws; ws.emplace_back(t);
+                w.callBoxed(ws);
+                t.mul_(1.0 / c.world);
+            }
+        }
+    }
+    // `waiter` waits for every collective handed over so far
+    void join(HStream waiter)
+    {
+        if (pending.empty()) return;
+        static auto w = op("_c10d_functional::wait_tensor");
+        StreamScope sc(waiter);
+        for (auto& t : pending) { torch::jit::Stack ws; ws.emplace_back(t); w.callBoxed(ws); }
+        pending.clear();
+    }
+};
 
 // parameter order (modules.py: SMIN._native_params): video encoder 3, LSTM 16, 20 per SMI layer, localization 8
 enum { P_VE_W = 0, P_VE_B, P_PE, P_LSTM = 3, P_LAYER0 = 19 };
@@ -675,7 +737,7 @@ Tensor sum_list(const std::vector<Tensor>& ts)
 }
 
 struct SminCore : torch::autograd::Function<SminCore> {
-    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4, F_BF16_OPERANDS = 8 };
+    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4, F_BF16_OPERANDS = 8, F_GRAD_SYNC = 16 };
     enum { N_FIXED = 13 };          // forward arguments ahead of the parameter list (tensors and scalars alike take one gradient slot)
 
     static variable_list forward(AutogradContext* ctx, Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask,
@@ -958,6 +1020,10 @@ struct SminCore : torch::autograd::Function<SminCore> {
         // of their own and fill the chip beside the bandwidth-bound kernels of the main chain
         HStream wstr = (flags & F_ASYNC_WEIGHTS) ? weight_stream(dev.index()) : curs;
         std::vector<Tensor> keep;                                                  // main-stream tensors read on wstr: alive until the streams join
+        GradSync sync;
+        sync.on = (flags & F_GRAD_SYNC) != 0;
+        TORCH_CHECK(!sync.on || prep_kernel, "smin_forward: the in-node gradient exchange needs the parameter-product kernel (D % 32 == 0, D <= 1056, dl % 32 == 0, <= 8 layers)");
+        TORCH_CHECK(!sync.on || !grad_sync_config().group.empty(), "smin_forward: grad_sync requested but no process group was set (smin_hip::set_grad_sync)");
         std::vector<Tensor> dprm(prm.size());
         auto dlp = [&](int64_t k, int which) -> Tensor& { return dprm[k * L_COUNT + which]; };
         auto acc = [](Tensor& into, const Tensor& t) { if (into.defined()) into.add_(t); else into = t; };
@@ -982,12 +1048,14 @@ struct SminCore : torch::autograd::Function<SminCore> {
         const Tensor& bu_last = st.layer[nl - 1].bu;
         Tensor dpm = g[0].defined() ? cont(g[0]) : at::zeros_like(st.pm), dpsea = g[1].defined() ? cont(g[1]) : at::zeros_like(st.psea);
         Tensor dfm = at::empty({N, D}, opt), dfb_next = at::empty({B, L, D}, opt);
+        std::vector<Tensor> loc_bufs;
         {
             Tensor dwm = at::empty({D}, opt), dbm = at::empty({1}, opt), dwb = at::empty({3, D}, opt), dbb = at::empty({3}, opt);
             auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
             SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), fp(dpsea), fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb), fp(lmf),
                                        fpm(dfm), fpm(dfb_next), fpm(dwm), fpm(dbm), fpm(dwb), fpm(dbb), ws.p, ws.n));
             Tensor* dloc = &dprm[nl * L_COUNT];
+            loc_bufs = {dwm, dbm, dwb, dbb};
             dloc[0] = dwm.view_as(loc[0]); dloc[1] = dbm.view_as(loc[1]);
             for (int h = 0; h < 3; ++h) { dloc[2 + 2 * h] = dwb[h].view_as(loc[2 + 2 * h]); dloc[3 + 2 * h] = dbb.slice(0, h, h + 1).view_as(loc[3 + 2 * h]); }
         }
@@ -1025,6 +1093,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                     dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
                     dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
                 }
+                sync.reduce({dWcat, dbcat}, wstr);                                   // inputs of the parameter-product kernel
             }
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
@@ -1048,6 +1117,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                                fp(qmf), fp(lmf), fp(ls.Qb), fp(ls.Kb), fp(ls.P), fp(ls.baq), fp(ls.bqv), fp(ls.A), fpm(dfb_k), fpm(dfw), fpm(dfs), fpm(dhbar_b),
                                                fpm(dWq), fpm(dbq), fpm(dWk), fpm(dbk), ws.p, ws.n));
                 dlp(k, L_BQ_W) = dWq; dlp(k, L_BQ_B) = dbq; dlp(k, L_BK_W) = dWk; dlp(k, L_BK_B) = dbk;
+                sync.reduce({dWq, dbq, dWk, dbk}, side);
                 dfs_parts.push_back(dfs); dfw_parts.push_back(dfw);
                 keep.push_back(dfb_next); keep.push_back(dfb_mu); keep.push_back(dhbar_b);
             }
@@ -1175,6 +1245,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                        dl, fpm(dfw), fpm(dfs), dp.data(), ws.p, ws.n));
             dfw_parts.push_back(dfw); dfs_parts.push_back(dfs);
             words_done = mark(tail);
+            if (sync.on) {
+                std::vector<Tensor> ws_grads = loc_bufs;
+                for (int64_t k = 0; k < nl; ++k)
+                    for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) ws_grads.push_back(dlp(k, which));
+                sync.reduce(ws_grads, tail);
+            }
         }
 
         // ---- clip-window terms of chat, the proposal map, f
@@ -1215,6 +1291,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
         // ---- parameter products on the second stream: consts_k = b_ch_k + Wch_k bsum_k (bsum_k = sum_{l<k} b_c_l), Pcat_k = [Wch_k Wc_l]_l
         if (tail != wstr) await(tail, weights_done);
+        if (sync.on) {
+            std::vector<Tensor> ins{dconsts_all, dWch_all};
+            for (int64_t k = 0; k < nl; ++k) {
+                ins.push_back(base_ch[k]); ins.push_back(base_c[k]); ins.push_back(base_bc[k]);
+                for (auto& t : dPcat[k]) ins.push_back(t);
+            }
+            sync.reduce(ins, tail);
+            sync.join(tail);                                                        // every input of the parameter products (the layers' dWcat included) is averaged
+        }
         if (prep_kernel) {
             StreamScope sc(tail);
             std::vector<const float*> pp, dpc(nl * 2, nullptr), bch(nl, nullptr), bc(nl), bbc(nl);
@@ -1254,7 +1339,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
 
         // ---- backbone on the main stream: video encoder, sentence / word features, the two LSTM layers (models.py:38-83)
-        std::vector<Tensor> dbb(P_LAYER0);
+        std::vector<Tensor> dbb(P_LAYER0), lstm_bufs;
         {
             const int Din = i32(st.vx.size(2));
             const int64_t pe_rows = all[P_PE].size(0);
@@ -1289,6 +1374,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 const int In = i32(ls.x.size(2)), Hh = i32(H);
                 Tensor dX = layer > 0 ? at::empty_like(ls.x) : Tensor();
                 Tensor dWih = at::empty_like(ls.Wih), dbias = at::empty({8 * H}, opt), dWhh = at::empty_like(ls.Whh);
+                lstm_bufs.push_back(dWih); lstm_bufs.push_back(dbias); lstm_bufs.push_back(dWhh);
                 Tensor wsl = own(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh));
                 SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
                                               fpm(dX), nullptr, nullptr, nullptr, wsl.data_ptr(), (size_t)wsl.numel()));
@@ -1308,6 +1394,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
         wait_stream(curs, tail);
         wait_stream(curs, wstr);
+        if (sync.on) {
+            std::vector<Tensor> late{dbb[P_VE_W], dbb[P_VE_B], dbb[P_PE]};
+            for (auto& t : lstm_bufs) late.push_back(t);
+            sync.reduce(late, curs);
+            sync.join(curs);
+        }
 
         variable_list out(N_FIXED + all.size());
         for (size_t i = 0; i < all.size(); ++i) out[N_FIXED + i] = i < (size_t)P_LAYER0 ? dbb[i] : dprm[i - P_LAYER0];
@@ -1341,7 +1433,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
     const Tensor* loc = &prm[P_LAYER0 + nl * L_COUNT];
     if (cfg.size() >= 11 && cfg[10] != 0 && !video_features.requires_grad() && !query_features.requires_grad()) {      // the whole model as one node
         const int64_t flags = (overlap_boundary ? SminCore::F_OVERLAP_BOUNDARY : 0) | (overlap_prep ? SminCore::F_OVERLAP_PREP : 0) |
-                              ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0) | ((cfg.size() >= 13 && cfg[12] != 0) ? SminCore::F_BF16_OPERANDS : 0);
+                              ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0) | ((cfg.size() >= 13 && cfg[12] != 0) ? SminCore::F_BF16_OPERANDS : 0) |
+                              ((cfg.size() >= 14 && cfg[13] != 0) ? SminCore::F_GRAD_SYNC : 0);
         auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
         Tensor psea = out[1];
         return std::make_tuple(out[0], psea[0], psea[1], psea[2]);
@@ -1513,4 +1606,10 @@ TORCH_LIBRARY(smin_hip, m)
     m.def("smin_loss(Tensor pm, Tensor ym, Tensor sm, Tensor moment_mask, Tensor ps, Tensor ys, Tensor ss, Tensor pe, Tensor ye, Tensor se, Tensor pa, Tensor ya, "
           "Tensor length_mask) -> Tensor", &smin_loss);
     m.def("abi_version() -> int", []() -> int64_t { return smin_abi_version(); });
+    // data parallel: the process group (c10d group name) the one-node backward averages its gradients over, see GradSync;
+    // cfg[13] of smin_forward switches the exchange on per call.  coalesced_avg: the backend takes grouped "avg" all-reduces (RCCL)
+    m.def("set_grad_sync(str group_name, int world, bool coalesced_avg) -> ()", [](std::string group, int64_t world, bool coalesced_avg) {
+        GradSyncConfig& c = grad_sync_config();
+        c.group = std::move(group); c.world = (int)world; c.coalesced_avg = coalesced_avg;
+    });
 }

@@ -42,9 +42,30 @@ def shard_batch(batch, rank, world):
     return out
 
 
+class InNodeDataParallel(torch.nn.Module):
+    """Data-parallel wrapper of a SMIN whose step is one autograd node (the default).  torch DDP would see every gradient only when
+    that node returns, so its all-reduce could not overlap the backward pass; here the node itself hands its gradient buffers to
+    the process group as they become final (csrc/torch_binding.cpp GradSync: RCCL grouped all-reduces on the producing stream,
+    joined before the node returns) and `.grad` holds the average over ranks when backward() returns.  Parameters are broadcast
+    from rank 0 at construction, like DDP does; `.module` is the wrapped model."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.module = model
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+        from . import _lib
+        _lib.load_torch().set_grad_sync(dist.group.WORLD.group_name, dist.get_world_size(), dist.get_backend() == "nccl")
+        model.grad_sync = True
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
 def wrap(model, device=None, bucket_cap_mb=8):
-    """DistributedDataParallel with small buckets so the all-reduce overlaps the backward kernels
-    (28-36 MB of fp32 gradients per step: SURVEY 5)."""
+    """Data parallel over the default process group (28-36 MB of fp32 gradients per step: SURVEY 5).  The one-node step
+    exchanges its gradients itself, overlapped with its backward pass (InNodeDataParallel); the node-per-module graph and
+    the Python host go through DistributedDataParallel with small buckets."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("SMIN_FORCE_DDP")):
         return model
     changed = {}
@@ -64,6 +85,11 @@ def wrap(model, device=None, bucket_cap_mb=8):
     if changed:
         log.warning("distributed.wrap (%s, world %d): set %s on the model", dist.get_backend(), dist.get_world_size(),
                     ", ".join(f"{k}={v}" for k, v in changed.items()))
+    in_node = (getattr(model, "fused_core", False) and getattr(model, "native_host", False) and hasattr(model, "_prep_is_library_code")
+               and model._prep_is_library_code() and not os.environ.get("SMIN_TORCH_DDP"))
+    model.grad_exchange = "in_node" if in_node else "torch_ddp"
+    if in_node:
+        return InNodeDataParallel(model)
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)

@@ -413,6 +413,8 @@ class SMIN(nn.Module):
 
     native_host = True             # run the in-model path as ONE torch-extension call (csrc/torch_binding.cpp); False: Python host
     async_weights = True           # ... whose weight-gradient contractions run on a low-priority stream of their own
+    grad_sync = False              # data parallel: the one-node backward averages its gradients over the process group itself, group by
+                                   # group as they become final (set by distributed.wrap; torch_binding.cpp GradSync)
     bf16_operand_storage = True    # under set_gemm_mode("bf16"): tensors that only feed contractions are stored as bf16 (no bit of the step changes)
     fused_core = True              # ... with proposal map + SMI layers + localization as one autograd node (False: a node per module)
     content_stream = True          # dl < D: keep the content stream in the dl-dimensional space (see _forward_stream)
@@ -568,11 +570,14 @@ class SMIN(nn.Module):
             raise ValueError(f"query_mask has {query_mask.shape[1]} columns for {query_features.shape[1]} words (max_query_length {self.max_query_length})")
         if query_mask.shape[1] < self.max_query_length:
             query_mask = torch.nn.functional.pad(query_mask, (0, self.max_query_length - query_mask.shape[1]))
+        if self.grad_sync and not (self._native_ok(video_features, query_features) and self.fused_core):
+            raise RuntimeError("SMIN.grad_sync (distributed.wrap's in-node gradient exchange) needs the one-node extension path; this "
+                               "call does not qualify (see SMIN._native_ok) -- wrap the model with SMIN_TORCH_DDP=1 instead")
         if self._native_ok(video_features, query_features):
             from . import _lib
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
                    int(self.overlap_boundary), int(self.overlap_prep and (self._streams_allowed("torch") or self._prep_is_library_code())), int(self.fused_core),
-                   int(self.async_weights), int(self.bf16_operand_storage)]
+                   int(self.async_weights), int(self.bf16_operand_storage), int(self.grad_sync and torch.is_grad_enabled())]
             return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
                                                   self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
