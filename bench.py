@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd only")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (training.CapturedStep; the host-bound small workloads)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra timings of the bf16-core contraction modes")
     ap.add_argument("--gemm", "--dtype", dest="gemm", default=os.environ.get("SMIN_GEMM_MODE", "f32"), choices=["f32", "f32e", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (f32 = the reference's, the headline; bf16 = BASELINE.json configs[1])")
@@ -178,7 +179,7 @@ def main():
         model.fused_core = False
     # main.py:78-83, activitynet.yml lr.  fused=True: torch's single-launch implementation of the same update (the default on a GPU
     # is the multi-tensor "foreach" form: ~10 launches and ~0.7 ms of host time per step); SMIN_FOREACH_ADAM=1 restores it
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=not os.environ.get("SMIN_FOREACH_ADAM"))
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=not os.environ.get("SMIN_FOREACH_ADAM"), capturable=bool(args.graph))
     net = dp.wrap(model, dev)                                 # DDP: bucketed gradient all-reduce overlapped with backward
     batch = make_batch(B, T, L, Nq, Din, seed=1000 + rank, device=dev)
     n_valid = int(batch["moment_mask"].sum().item())
@@ -197,8 +198,15 @@ def main():
         feeder = models.vml_amd.BatchFeeder(T, L, Nq, dev)
         feed_iter = feeder.feed(itertools.cycle(hosts))
 
-    def step(with_opt=True):
+    captured = {}
+    if args.graph:
+        assert world == 1 and feed_iter is None, "--graph: one GPU, resident inputs"
+        captured = {True: models.vml_amd.CapturedStep(model, None if args.no_optimizer else opt), False: models.vml_amd.CapturedStep(model, None)}
+
+    def step(with_opt=True, eager=False):
         nonlocal batch
+        if captured and not eager:
+            return captured[with_opt and not args.no_optimizer](batch)[0]
         if feed_iter is not None:
             batch = next(feed_iter)
             batch["sm"] = torch.nan_to_num(batch["sm"])       # 0/0 IoU of degenerate windows (the reference has the same NaNs)
@@ -228,6 +236,13 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.prof_enable(False)
     prof = lib.prof_read()
+    if captured:                                              # a replay runs no host code, so no launch is bracketed: kernel timings from eager steps
+        lib.prof_enable(True)
+        for _ in range(5):
+            step(with_opt=False, eager=True)
+        fence()
+        lib.prof_enable(False)
+        prof = lib.prof_read()
     elapsed = dp.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
     # the same K steps without the optimizer: SURVEY 8d defines the metric on zero_grad + fwd + loss + bwd (+ all-reduce)
     fence()
@@ -241,10 +256,10 @@ def main():
     prof_serial = {}
     if getattr(model, "async_weights", False) and getattr(model, "fused_core", False):
         model.async_weights = False
-        step(with_opt=False)
+        step(with_opt=False, eager=True)
         lib.prof_enable(True)
         for _ in range(max(2, args.steps // 4)):
-            step(with_opt=False)
+            step(with_opt=False, eager=True)
         fence()
         lib.prof_enable(False)
         prof_serial = lib.prof_read()
@@ -407,7 +422,8 @@ def main():
             "data": "synthetic" if args.feed == "resident" else "synthetic, fed from pinned host memory every step (BatchFeeder: async H2D + device-side targets)",
             "config": {"workload": f"{args.workload}: SMIN T={T} L={L} C={C} d={D} dl={dl} Nq={Nq} Din={Din} layers={layers}, "
                                    f"batch {B}/GPU, default init seed 43; step = zero_grad+fwd+restated loss+bwd"
-                                   + ("" if args.no_optimizer else "+Adam (torch fused)" if not os.environ.get("SMIN_FOREACH_ADAM") else "+Adam (torch foreach)") + exchange,
+                                   + ("" if args.no_optimizer else "+Adam (torch fused)" if not os.environ.get("SMIN_FOREACH_ADAM") else "+Adam (torch foreach)") + exchange
+                                   + (", replayed as one HIP graph per (shapes, valid-cell count) with one scalar device read ahead of each step (training.CapturedStep)" if args.graph else ""),
                        "global_batch": total_B, "valid_cells_per_step": n_valid_total,
                        "valid_cells_per_s": n_valid_total / (elapsed / args.steps), "parallelism": f"dp{world}", "dist_backend": backend, "dist_world_size": world_seen,
                        "ddp_overrides": getattr(model, "ddp_overrides", None), "grad_exchange": getattr(model, "grad_exchange", None),

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define SMIN_HIP_ABI_VERSION 1
+/* 2 (round 3): smin_build_cells_n; content attention requires dl % 16 == 0; round-2 changes that were not versioned:
+ * smin_linear_rows_bwd accepts dW == NULL, smin_video_encoder_bwd / smin_bilstm_layer_bwd may be issued as two halves */
+#define SMIN_HIP_ABI_VERSION 2
 
 int smin_abi_version(void);
 /* Arithmetic of the dense contractions (forward maps, input gradients, weight gradients):
@@ -333,6 +335,11 @@ int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, cons
  * [B*L + 1]; cellmap [B][L][L] = cell id or -1.  The caller sizes cells from the count of listed cells. */
 int smin_build_cells(void* stream, const uint8_t* mask, int B, int L, int all_cells,
                      int32_t* cells, int32_t* row_ptr, int32_t* cellmap);
+/* The same for a caller that already knows the number of listed cells (a captured step replays with the count it was captured
+ * for: no device -> host round trip inside the step).  cells holds exactly n_expected entries; nothing is written past it, and
+ * *status (device int32, cleared once by the caller) is set to 1 if the mask lists a different number of cells. */
+int smin_build_cells_n(void* stream, const uint8_t* mask, int B, int L, int all_cells, int n_expected,
+                       int32_t* cells, int32_t* row_ptr, int32_t* cellmap, int32_t* status);
 
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);

@@ -1196,3 +1196,55 @@ def test_layout_build_kernels(dev):
         assert got_all.N == B * L * L and not got_all.all_valid
         for name in ("cells", "row_ptr", "cellmap"):
             assert torch.equal(getattr(got_all, name).cpu(), getattr(ref_all, name)), (B, L, name, "all")
+
+
+# ---------------------------------------------------------------- the captured step (training.CapturedStep)
+def test_captured_step_bit_identical_to_eager(dev):
+    """One HIP graph per (shapes, valid-cell count): scores, loss and every gradient of a replay equal the eager step's bit for bit,
+    a second batch with the same count replays the same graph, a batch with another count gets its own, and a wrong
+    known_cell_count is flagged instead of writing out of bounds."""
+    import models
+    from oracle import smin_oracle as O                         # seeded inputs and weights only
+    from vml_amd import CapturedStep, loss_fn
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 64, 16, 4, 128, 32, 3, 40, 9, 64, 4
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+
+    def eager(b):
+        for p in m.parameters():
+            p.grad = None
+        out = m(*H.model_inputs(b))
+        loss = loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"])
+        loss.backward()
+        return loss.detach().clone(), [o.detach().clone() for o in out], [p.grad.clone() for p in m.parameters()]
+
+    b1 = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=11).items()}
+    # a second batch with the same masks (hence the same count) and other values
+    b2 = dict(b1)
+    g = torch.Generator().manual_seed(5)
+    b2["video_features"] = (torch.randn(b1["video_features"].shape, generator=g).to(dev) * b1["video_mask"].float())
+    b2["sm"] = (torch.rand(b1["sm"].shape, generator=g).to(dev) * b1["moment_mask"])
+    b3 = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=12).items()}     # other lengths: another count
+    assert int(b3["moment_mask"].sum()) != int(b1["moment_mask"].sum())
+    step = CapturedStep(m, None)
+    for b in (b1, b2, b3, b1):
+        want = eager(b)
+        loss, out = step(b)
+        torch.cuda.synchronize()
+        assert torch.equal(loss.detach(), want[0])
+        for a, w in zip(out, want[1]):
+            assert torch.equal(a.detach(), w)
+        for p, w in zip(m.parameters(), want[2]):
+            assert torch.equal(p.grad, w)
+    assert len(step.entries) == 2                                  # b1 / b2 share a graph
+    # a wrong count: flagged, in bounds
+    ops = models.vml_amd._lib.load_torch()
+    status = ops.layout_status(dev)
+    m.known_cell_count = int(b1["moment_mask"].sum()) + 7
+    try:
+        m(*H.model_inputs(b1))
+        torch.cuda.synchronize()
+        assert int(status.item()) == 1
+    finally:
+        m.known_cell_count = None
+        status.zero_()

@@ -78,7 +78,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} declared in smin_hip.h but not exported"
     assert declared == set(models.vml_amd._lib.SIGNATURES), "ctypes table and header disagree"
     loaded = models.vml_amd._lib.load()
-    assert loaded.smin_abi_version() == 1 and loaded.smin_target_arch() == b"gfx950"
+    assert loaded.smin_abi_version() == 2 and loaded.smin_target_arch() == b"gfx950"
     assert loaded.smin_workspace_bytes(1000, 2, 4, 512, 128, 20) > 0
 
 
@@ -87,7 +87,7 @@ def test_torch_extension_registers_operators():
     schemas, and refuses CPU tensors (no CPU fallback behind the extension either)."""
     import models
     ops = models.vml_amd._lib.load_torch()
-    assert ops.abi_version() == 1
+    assert ops.abi_version() == 2
     schema = str(torch.ops.smin_hip.smin_forward.default._schema)
     for name in ("video_features", "video_mask", "query_features", "query_mask", "length_mask", "moment_mask", "Tensor[] params", "int[] cfg"):
         assert name in schema, schema

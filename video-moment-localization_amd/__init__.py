@@ -23,6 +23,6 @@ from .modules import (  # noqa: F401
     SMIN, SMI, Attention, Backbone, BoundaryUnit, ContentAttention, ContentUnit, Localization,
     MomentUnit, ProposalGeneration, QueryEncoder, VideoEncoder, compute_content_matrix,
 )
-from .training import loss_fn, loss_fn_torch, bce_loss, compute_ious, compute_ious_torch  # noqa: F401
+from .training import loss_fn, loss_fn_torch, bce_loss, compute_ious, compute_ious_torch, CapturedStep  # noqa: F401
 from .labels import build_targets  # noqa: F401
 from .feeder import BatchFeeder, build_targets_hip  # noqa: F401

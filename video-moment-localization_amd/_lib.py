@@ -12,6 +12,7 @@ TORCH_LIB_PATH = os.path.join(_HERE, "libsmin_torch.so")        # TORCH_LIBRARY(
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+ABI_VERSION = 2                                                 # include/smin_hip.h SMIN_HIP_ABI_VERSION
 
 # name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/smin_hip.h one to one
 SIGNATURES = {
@@ -56,6 +57,7 @@ SIGNATURES = {
     "smin_word_prep_bwd_workspace_bytes": [_i] * 5,
     "smin_word_prep_bwd": [_vp] * 11 + [_i] * 5 + [_vp] * 3 + [_vp, _sz],
     "smin_build_cells": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "smin_build_cells_n": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "smin_pack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_unpack_cells": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_gemm_nt": [_vp] * 4 + [_i] * 3,
@@ -120,7 +122,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, _i)
-    if lib.smin_abi_version() != 1:
+    if lib.smin_abi_version() != ABI_VERSION:
         raise SminHipError("libsmin_hip.so ABI version mismatch")
     _lib = lib
     if DEFAULT_GEMM_MODE != "f32":                        # deployment switch: SMIN_GEMM_MODE=f32e|bf16x3|bf16 (see set_gemm_mode)
@@ -144,7 +146,7 @@ def load_torch():
             "(or set SMIN.native_host = False to drive the same kernels from the Python host)")
     torch.ops.load_library(TORCH_LIB_PATH)
     ops = torch.ops.smin_hip
-    if ops.abi_version() != 1:
+    if ops.abi_version() != ABI_VERSION:
         raise SminHipError("libsmin_torch.so / libsmin_hip.so ABI version mismatch")
     _torch_ops = ops
     return ops

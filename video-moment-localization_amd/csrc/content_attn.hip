@@ -469,7 +469,7 @@ void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restri
 
     for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
         const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
-        const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
+        const int seg_end = max(n + 1, min(n_hi, row_ptr[(b + 1) * L]));      // (a well-formed list ends its sample past n; never step back)
         __syncthreads();                                          // the previous segment's tiles are done with the LDS images
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                             // not loop-invariant as far as the compiler knows (see stage_slot_major)
@@ -654,7 +654,7 @@ void content_attn_bwd_kernel(const float* __restrict__ chat, const float* __rest
 
     for (int n = n_lo; n < n_hi;) {                               // one iteration per sample the range touches
         const int b = __builtin_amdgcn_readfirstlane(cells[4 * (size_t)n]);
-        const int seg_end = min(n_hi, row_ptr[(b + 1) * L]);
+        const int seg_end = max(n + 1, min(n_hi, row_ptr[(b + 1) * L]));      // (a well-formed list ends its sample past n; never step back)
         __syncthreads();
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                             // not loop-invariant as far as the compiler knows (see stage_slot_major)

@@ -43,10 +43,18 @@ void layout_rows_kernel(const uint8_t* __restrict__ mask, int rows, int L, int a
 }
 
 // one wave per row (b, i): compacts the listed j's by ballot rank
+// n_cap >= 0: the caller sized `cells` for exactly n_cap entries without asking the device (a captured step replays with the count
+// it was captured for): nothing is written past n_cap, entries the mask does not fill are set to an inert in-range cell, and
+// *status becomes 1 when the mask lists a different number of cells -- the step's results are then meaningless, but in bounds.
 __global__ __launch_bounds__(256)
 void layout_fill_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ row_ptr, int rows, int L, int all_cells,
-                        int* __restrict__ cells, int* __restrict__ cellmap)
+                        int* __restrict__ cells, int* __restrict__ cellmap, int n_cap, int* __restrict__ status)
 {
+    if (n_cap >= 0 && blockIdx.x == 0) {
+        const int total = row_ptr[rows];
+        if (threadIdx.x == 0 && total != n_cap) *status = 1;
+        for (int id = total + (int)threadIdx.x; id < n_cap; id += 256) *reinterpret_cast<int4*>(cells + 4 * (size_t)id) = make_int4(0, 0, 0, 0);
+    }
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= rows) return;
     const int b = r / L, i = r - b * L;
@@ -58,11 +66,12 @@ void layout_fill_kernel(const uint8_t* __restrict__ mask, const int* __restrict_
         const bool listed = in && (all_cells || flag);
         const unsigned long long bal = __ballot(listed);
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-        if (listed) {
+        const bool stored = listed && (n_cap < 0 || n + rank < n_cap);
+        if (stored) {
             const int id = n + rank;
             *reinterpret_cast<int4*>(cells + 4 * (size_t)id) = make_int4(b, i, j, flag ? 1 : 0);
         }
-        if (in) cellmap[(size_t)r * L + j] = listed ? n + rank : -1;
+        if (in) cellmap[(size_t)r * L + j] = stored ? n + rank : -1;
         n += __popcll(bal);
     }
 }
@@ -81,7 +90,23 @@ extern "C" int smin_build_cells(void* stream, const uint8_t* mask, int B, int L,
     const int rows = B * L;
     hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(1024), 0, st, mask, rows, L, all_cells, row_ptr);
     SMIN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(layout_fill_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, mask, row_ptr, rows, L, all_cells, cells, cellmap);
+    hipLaunchKernelGGL(layout_fill_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, mask, row_ptr, rows, L, all_cells, cells, cellmap, -1, (int*)nullptr);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same for a caller that knows the number of listed cells already (n_expected, e.g. a captured step: no device -> host round
+// trip inside the step).  `cells` holds exactly n_expected entries; *status (device, int32) is set to 1 if the mask lists another
+// number -- see layout_fill_kernel.  The caller clears *status once and reads it when convenient.
+extern "C" int smin_build_cells_n(void* stream, const uint8_t* mask, int B, int L, int all_cells, int n_expected,
+                                  int32_t* cells, int32_t* row_ptr, int32_t* cellmap, int32_t* status)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(B >= 1 && L >= 1 && n_expected >= 0 && status != nullptr);
+    const int rows = B * L;
+    hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(1024), 0, st, mask, rows, L, all_cells, row_ptr);
+    SMIN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(layout_fill_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, mask, row_ptr, rows, L, all_cells, cells, cellmap, n_expected, status);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

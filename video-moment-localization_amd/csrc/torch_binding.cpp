@@ -157,6 +157,17 @@ std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, 
 
 Tensor undef() { return Tensor(); }
 
+// device word that smin_build_cells_n sets when a caller-supplied cell count does not match the mask (see csrc/layout.hip)
+Tensor layout_status(const at::Device& dev)
+{
+    static std::mutex mu;
+    static std::map<int, Tensor> st;
+    std::lock_guard<std::mutex> lk(mu);
+    Tensor& t = st[(int)dev.index()];
+    if (!t.defined()) t = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+    return t;
+}
+
 // ---------------------------------------------------------------- gradient exchange inside the node (data parallel)
 // With the whole model as one autograd node torch DDP sees every gradient only when the node returns: its all-reduce would start
 // after the backward pass.  Instead the node hands each group of finished gradient buffers to the process group itself
@@ -808,10 +819,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
         st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});      // (two tiny torch launches, main stream)
         bb = at::cat({loc[3], loc[5], loc[7]});
 
-        // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued
+        // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued -- unless the
+        // caller already knows it (flags >> 16 = count + 1; a captured step: nothing inside may wait for the device)
+        const int64_t n_known = (flags >> 16) - 1;
         Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
-        Tensor host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-        host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+        Tensor host_n;
+        if (n_known < 0) {
+            host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+            host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+        }
         hipEvent_t count_ready = next_event();
         TORCH_CHECK(hipEventRecord(count_ready, curs.stream()) == hipSuccess, "hipEventRecord failed");
 
@@ -849,8 +865,8 @@ struct SminCore : torch::autograd::Function<SminCore> {
         SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), fp(fs), B, Ti, i32(st.vx.size(2)), D, fpm(st.fv), fpm(f)));
 
         // ---- layout, part 2
-        TORCH_CHECK(hipEventSynchronize(count_ready) == hipSuccess, "hipEventSynchronize failed");
-        const int64_t N = host_n.const_data_ptr<int64_t>()[0];
+        if (n_known < 0) TORCH_CHECK(hipEventSynchronize(count_ready) == hipSuccess, "hipEventSynchronize failed");
+        const int64_t N = n_known < 0 ? host_n.const_data_ptr<int64_t>()[0] : n_known;
         const int n = i32(N);
         Tensor cells, row_ptr, cellmap;
         Tensor mask8 = mm.contiguous().view(at::kByte);
@@ -860,8 +876,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
             StreamScope sc(prep);
             auto io = at::TensorOptions().dtype(at::kInt).device(dev);
             cells = at::empty({N, 4}, io); row_ptr = at::empty({Bq * L + 1}, io); cellmap = at::empty({Bq, L, L}, io);
-            SMIN_CK(smin_build_cells(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), B, Li, 0, cells.data_ptr<int32_t>(), row_ptr.data_ptr<int32_t>(),
-                                     cellmap.data_ptr<int32_t>()));
+            if (n_known < 0)
+                SMIN_CK(smin_build_cells(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), B, Li, 0, cells.data_ptr<int32_t>(), row_ptr.data_ptr<int32_t>(),
+                                         cellmap.data_ptr<int32_t>()));
+            else
+                SMIN_CK(smin_build_cells_n(cur(), static_cast<const uint8_t*>(mask8.const_data_ptr()), B, Li, 0, n, cells.data_ptr<int32_t>(), row_ptr.data_ptr<int32_t>(),
+                                           cellmap.data_ptr<int32_t>(), layout_status(dev).data_ptr<int32_t>()));
             layout_ready = mark(prep);
         }
         Tensor qmf = cont(fl(qm)), lmf = cont(fl(length_mask));
@@ -1434,7 +1454,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
     if (cfg.size() >= 11 && cfg[10] != 0 && !video_features.requires_grad() && !query_features.requires_grad()) {      // the whole model as one node
         const int64_t flags = (overlap_boundary ? SminCore::F_OVERLAP_BOUNDARY : 0) | (overlap_prep ? SminCore::F_OVERLAP_PREP : 0) |
                               ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0) | ((cfg.size() >= 13 && cfg[12] != 0) ? SminCore::F_BF16_OPERANDS : 0) |
-                              ((cfg.size() >= 14 && cfg[13] != 0) ? SminCore::F_GRAD_SYNC : 0);
+                              ((cfg.size() >= 14 && cfg[13] != 0) ? SminCore::F_GRAD_SYNC : 0) |
+                              ((cfg.size() >= 15 && cfg[14] >= 0) ? ((cfg[14] + 1) << 16) : 0);      // cfg[14]: the number of valid cells, when the caller knows it
         auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
         Tensor psea = out[1];
         return std::make_tuple(out[0], psea[0], psea[1], psea[2]);
@@ -1606,6 +1627,8 @@ TORCH_LIBRARY(smin_hip, m)
     m.def("smin_loss(Tensor pm, Tensor ym, Tensor sm, Tensor moment_mask, Tensor ps, Tensor ys, Tensor ss, Tensor pe, Tensor ye, Tensor se, Tensor pa, Tensor ya, "
           "Tensor length_mask) -> Tensor", &smin_loss);
     m.def("abi_version() -> int", []() -> int64_t { return smin_abi_version(); });
+    // the status word of smin_build_cells_n on a device (non-zero after a step whose cfg[14] cell count did not match its mask)
+    m.def("layout_status(Device device) -> Tensor", [](c10::Device dev) { return layout_status(dev); });
     // data parallel: the process group (c10d group name) the one-node backward averages its gradients over, see GradSync;
     // cfg[13] of smin_forward switches the exchange on per call.  coalesced_avg: the backend takes grouped "avg" all-reduces (RCCL)
     m.def("set_grad_sync(str group_name, int world, bool coalesced_avg) -> ()", [](std::string group, int64_t world, bool coalesced_avg) {

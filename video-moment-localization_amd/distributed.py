@@ -85,8 +85,13 @@ def wrap(model, device=None, bucket_cap_mb=8):
     if changed:
         log.warning("distributed.wrap (%s, world %d): set %s on the model", dist.get_backend(), dist.get_world_size(),
                     ", ".join(f"{k}={v}" for k, v in changed.items()))
+    # The bf16-core contraction modes keep torch DDP (its all-reduce starts after the node has joined its streams): RCCL's
+    # reduction kernels are not built under this library's no-packed-fp32 rule (csrc/Makefile) and have not been
+    # checked beside the bf16 contraction kernels on a multi-GPU node, so they do not run beside them.
+    from . import _lib
     in_node = (getattr(model, "fused_core", False) and getattr(model, "native_host", False) and hasattr(model, "_prep_is_library_code")
-               and model._prep_is_library_code() and not os.environ.get("SMIN_TORCH_DDP"))
+               and model._prep_is_library_code() and not os.environ.get("SMIN_TORCH_DDP")
+               and (_lib.get_gemm_mode() == "f32" or bool(os.environ.get("SMIN_STREAMS_IN_ALL_MODES"))))
     model.grad_exchange = "in_node" if in_node else "torch_ddp"
     if in_node:
         return InNodeDataParallel(model)

@@ -413,6 +413,8 @@ class SMIN(nn.Module):
 
     native_host = True             # run the in-model path as ONE torch-extension call (csrc/torch_binding.cpp); False: Python host
     async_weights = True           # ... whose weight-gradient contractions run on a low-priority stream of their own
+    known_cell_count = None        # number of valid cells of the next batches' moment_mask, when the caller knows it: the forward then
+                                   # asks the device nothing (training.CapturedStep); a wrong value is flagged, see csrc/layout.hip
     grad_sync = False              # data parallel: the one-node backward averages its gradients over the process group itself, group by
                                    # group as they become final (set by distributed.wrap; torch_binding.cpp GradSync)
     bf16_operand_storage = True    # under set_gemm_mode("bf16"): tensors that only feed contractions are stored as bf16 (no bit of the step changes)
@@ -570,6 +572,9 @@ class SMIN(nn.Module):
             raise ValueError(f"query_mask has {query_mask.shape[1]} columns for {query_features.shape[1]} words (max_query_length {self.max_query_length})")
         if query_mask.shape[1] < self.max_query_length:
             query_mask = torch.nn.functional.pad(query_mask, (0, self.max_query_length - query_mask.shape[1]))
+        if self.grad_sync and not self._streams_allowed("torch"):
+            raise RuntimeError("SMIN.grad_sync: the in-node gradient exchange runs RCCL beside the contraction kernels and is limited to the exact "
+                               "fp32 mode; call distributed.wrap after set_gemm_mode (it then uses torch DDP)")
         if self.grad_sync and not (self._native_ok(video_features, query_features) and self.fused_core):
             raise RuntimeError("SMIN.grad_sync (distributed.wrap's in-node gradient exchange) needs the one-node extension path; this "
                                "call does not qualify (see SMIN._native_ok) -- wrap the model with SMIN_TORCH_DDP=1 instead")
@@ -577,7 +582,8 @@ class SMIN(nn.Module):
             from . import _lib
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
                    int(self.overlap_boundary), int(self.overlap_prep and (self._streams_allowed("torch") or self._prep_is_library_code())), int(self.fused_core),
-                   int(self.async_weights), int(self.bf16_operand_storage), int(self.grad_sync and torch.is_grad_enabled())]
+                   int(self.async_weights), int(self.bf16_operand_storage), int(self.grad_sync and torch.is_grad_enabled()),
+                   -1 if self.known_cell_count is None else int(self.known_cell_count)]
             return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
                                                   self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)

@@ -76,3 +76,102 @@ def compute_ious(pm, ps, pe, moment_mask, sm, n=(1, 5), m=(0.1, 0.3, 0.5, 0.7)):
         vals = counts.tolist()
         return {f"R@{n_}, IoU={m_}": vals[a * 4 + c] for a, n_ in enumerate(n) for c, m_ in enumerate(m)}
     return compute_ious_torch(pm, ps, pe, moment_mask, sm, n, m)
+
+
+MODEL_INPUTS = ("video_features", "video_mask", "query_features", "query_mask", "length_mask", "moment_mask")
+LOSS_TARGETS = ("ym", "sm", "ys", "ss", "ye", "se", "ya")
+
+
+class CapturedStep:
+    """The train step of the reference's loop (main.py:141-160: zero_grad -> forward -> loss -> backward -> optimizer.step) replayed
+    as ONE HIP graph.  The small configurations are bound by the host, not the device: ~210 launches of ~15 us of work each cost
+    2.8 ms (tacos.yml) / 3.4 ms (charadessta.yml) per step when every launch is issued by the interpreter; a graph replay issues
+    them from the driver.
+
+    What makes the step capturable: nothing inside it may wait for the device, and the one value the forward normally asks the
+    device for is the number of valid cells of ``moment_mask`` (it sizes every per-cell tensor).  Here it is read BEFORE the step
+    (one scalar read per call) and handed to the model (``SMIN.known_cell_count``); a graph is captured per (tensor shapes, cell
+    count) and kept (``max_graphs``, least recently used evicted).  Batches of full-length videos -- the common case: the
+    reference's dataset resamples every video longer than T to exactly T frames (dataset.py:40-74) -- share one count; a batch
+    with a count not seen before is captured on first sight (three eager steps + the capture).  Limits: the optimizer must be
+    capturable (``torch.optim.Adam(..., capturable=True)``); not combined with data parallel (collectives inside a captured
+    step are not handled here).  Opt-in: results are bit-identical to the eager step (tests/test_hip_parity.py).
+
+        step = CapturedStep(model, optimizer)
+        loss, (pm, ps, pe, pa) = step(batch)        # batch: dict with MODEL_INPUTS + LOSS_TARGETS; outputs are the graph's
+                                                    # static tensors, overwritten by the next call
+    """
+
+    def __init__(self, model, optimizer=None, max_graphs=4, warmup=3):
+        if getattr(model, "grad_sync", False):
+            raise ValueError("CapturedStep: not combined with the in-node gradient exchange")
+        self.model, self.optimizer, self.max_graphs, self.warmup = model, optimizer, max_graphs, warmup
+        self.entries = {}                                          # key -> dict(graph, static, loss, outputs, used)
+        self.clock = 0
+
+    @staticmethod
+    def _key(batch, n):
+        return (n,) + tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in MODEL_INPUTS + LOSS_TARGETS)
+
+    def _run(self, b):
+        from . import _lib  # noqa: F401
+        if self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            for p in self.model.parameters():
+                p.grad = None
+        out = self.model(*[b[k] for k in MODEL_INPUTS])
+        pm, ps, pe, pa = out
+        loss = loss_fn(pm, b["ym"], b["sm"], b["moment_mask"], ps, b["ys"], b["ss"], pe, b["ye"], b["se"], pa, b["ya"], b["length_mask"])
+        loss.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss, out
+
+    def __call__(self, batch):
+        dev = batch["moment_mask"].device
+        _require_hip(batch["moment_mask"], "CapturedStep")
+        from . import _lib
+        status = _lib.load_torch().layout_status(dev)
+        # the one device -> host read of the step, ahead of it (it also orders this call behind the previous replay)
+        n, bad = (int(v) for v in torch.stack([(batch["moment_mask"] != 0).sum().to(torch.int64), status[0].to(torch.int64)]).tolist())
+        if bad:
+            status.zero_()
+            raise RuntimeError("CapturedStep: the previous step ran with a cell count that did not match its moment_mask")
+        key = self._key(batch, n)
+        self.clock += 1
+        e = self.entries.get(key)
+        if e is None:
+            e = self._capture(batch, n, key)
+        else:
+            for k in MODEL_INPUTS + LOSS_TARGETS:
+                e["static"][k].copy_(batch[k], non_blocking=True)
+        e["used"] = self.clock
+        self.model.known_cell_count = n                            # (for an eager call right after; the graph has it baked in)
+        e["graph"].replay()
+        self.model.known_cell_count = None
+        return e["loss"], e["outputs"]
+
+    def _capture(self, batch, n, key):
+        if len(self.entries) >= self.max_graphs:
+            del self.entries[min(self.entries, key=lambda k: self.entries[k]["used"])]
+        static = {k: batch[k].clone() for k in MODEL_INPUTS + LOSS_TARGETS}
+        self.model.known_cell_count = n
+        try:
+            # torch's capture protocol: a few eager steps on a side stream first (allocator pools, lazily built tables and kernel
+            # attributes, the optimizer's state), then the capture.  NOTE: these steps update the parameters like any other step.
+            s = torch.cuda.Stream(device=static["moment_mask"].device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):
+                    self._run(static)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, out = self._run(static)
+        finally:
+            self.model.known_cell_count = None
+        e = dict(graph=g, static=static, loss=loss, outputs=out, used=self.clock)
+        self.entries[key] = e
+        return e
