@@ -217,7 +217,9 @@ int smin_loss_bwd(void* stream, const float* dloss, const float* part,
  * moment_mask [B][L][L], sm [B][L][L] fp32, ym, ss / se [B][L] fp32, ys, ye, ya.  Requires L | T. */
 int smin_build_targets(void* stream, const float* times, const float* duration, const int32_t* nfeats, const int32_t* qlen, int B, int T, int L, int Nq,
                        uint8_t* video_mask, uint8_t* query_mask, uint8_t* length_mask, uint8_t* moment_mask, float* sm, uint8_t* ym,
-                       float* ss, uint8_t* ys, float* se, uint8_t* ye, uint8_t* ya);
+                       float* ss, uint8_t* ys, float* se, uint8_t* ye, uint8_t* ya,
+                       const float* two_sigma_sq /* [B] or NULL: 2 sigma^2 of the boundary Gaussians as computed in double from the unrounded
+                                                    annotation times (dataset.py:116-119); NULL: formed in double from the fp32 times */);
 
 /* ---- compute_ious (reference utils.py:10-31): counts [8] = number of samples with a hit for
  * R@1 x IoU {0.1, 0.3, 0.5, 0.7} then R@5 x the same; ws [B][8] scratch.  Any L with L*L >= 5 (the reference's topk(5) needs as many). */

@@ -334,6 +334,17 @@ def test_target_kernel_and_feeder(dev):
                         src = {"ym": "sm", "ys": "ss", "ye": "se"}.get(k)
                         assert src is not None, (T, L, b, k)
                         assert ((ref[src][a != v] - 0.5).abs() < 1e-5).all(), (T, L, b, k)
+    # annotation times in double (what a loader has): the Gaussian denominators are formed in double and rounded once, as
+    # dataset.py:116-119 does in Python floats -- tighter agreement than through fp32 times
+    T, L, Nq, B = 64, 16, 9, 5
+    dur = torch.rand(B, generator=g) * 100 + 5
+    ts64 = torch.rand(B, generator=g, dtype=torch.float64) * dur.double() * 0.5
+    te64 = ts64 + 0.37 + torch.rand(B, generator=g, dtype=torch.float64) * 3.0
+    got = V.build_targets_hip(torch.stack([ts64, te64], 1).to(dev), dur.to(dev), torch.full((B,), T).to(dev), None, T, L, Nq)
+    for b in range(B):
+        ref = LO.sample_targets(float(ts64[b]), float(te64[b]), float(dur[b]), T, T, L)
+        for k in ("ss", "se"):
+            assert torch.allclose(got[k][b].cpu(), ref[k], rtol=2e-6, atol=1e-30), (b, k)
     # the feeder
     T, L, Nq, Din, B = 64, 16, 9, 40, 4
     hbs = []
@@ -1248,3 +1259,34 @@ def test_captured_step_bit_identical_to_eager(dev):
     finally:
         m.known_cell_count = None
         status.zero_()
+
+
+# ---------------------------------------------------------------- the two attention classes on their own
+def test_standalone_attention_classes_against_oracle(dev):
+    """Attention (reference models.py:128-154) and ContentAttention (models.py:198-226) as stand-alone modules: outputs and the
+    gradients of inputs and parameters against the oracle's word attention on the same seeded inputs, with a partly masked
+    query (including B = 1, where the reference's mask.squeeze() mis-shapes)."""
+    import models
+    from oracle import smin_oracle as O
+    g = torch.Generator().manual_seed(21)
+    for B in (3, 1):
+        L, C, D, Nq = 6, 4, 32, 7
+        qmask = torch.ones(B, Nq, 1, dtype=torch.uint8)
+        qmask[B - 1, 4:] = 0
+        key = torch.randn(B, Nq, D, generator=g) * qmask.float()
+        for cls, query in ((models.Attention, torch.randn(B, L, D, generator=g)), (models.ContentAttention, torch.randn(B, L, L, C, D, generator=g))):
+            mod = cls(D)
+            sd = {"x." + k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+            q0, k0 = query.clone().requires_grad_(True), key.clone().requires_grad_(True)
+            want = O._word_attention(sd, "x.", q0.reshape(B, -1, D), k0, k0, qmask.reshape(B, 1, Nq).float(), D).reshape(query.shape)
+            w = torch.randn(want.shape, generator=g)
+            (want * w).sum().backward()
+            mod = mod.to(dev)
+            q1, k1 = query.to(dev).requires_grad_(True), key.to(dev).requires_grad_(True)
+            got = mod(q1, k1, k1, qmask.to(dev))
+            (got * w.to(dev)).sum().backward()
+            assert rel_err(got.detach().cpu(), want.detach()) < 1e-5, cls.__name__
+            assert rel_err(q1.grad.cpu(), q0.grad) < 1e-4 and rel_err(k1.grad.cpu(), k0.grad) < 1e-4, cls.__name__
+            for name, p in mod.named_parameters():
+                ref = sd["x." + name].grad
+                assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6, (cls.__name__, name)

@@ -247,3 +247,17 @@ def test_library_has_no_packed_fp32_arithmetic(tmp_path):
         assert not bad, (os.path.basename(o), bad[:3])
         mfma += dis.count("v_mfma_f32_32x32x16_bf16")
     assert mfma > 0                                   # (the disassembly really covers the contraction kernels)
+
+
+def test_constructor_names_the_kernel_limits():
+    """Shapes outside what the HIP kernels hold are refused at construction with the limit named, not from the
+    middle of a forward pass."""
+    import models
+    import pytest
+    ok = dict(T=16, L=8, C=4, D=32, dl=16, num_smi_layers=2, input_video_dim=24, max_query_length=5, lstm_hidden_size=16)
+    models.SMIN(**ok)
+    for key, val, word in (("max_query_length", 33, "max_query_length <= 32"), ("dl", 136, "dl a multiple of 16"), ("dl", 24, "dl a multiple of 16"),
+                           ("C", 5, "2 <= C <= 4"), ("L", 5, "L | T")):
+        with pytest.raises(ValueError, match="limits of the HIP kernels") as e:
+            models.SMIN(**{**ok, key: val})
+        assert word in str(e.value)

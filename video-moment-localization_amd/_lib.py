@@ -52,7 +52,7 @@ SIGNATURES = {
     "smin_loss_fwd": [_vp] * 14 + [_i] * 2 + [_vp] * 2,
     "smin_loss_bwd": [_vp] * 16 + [_i] * 2 + [_vp] * 4,
     "smin_compute_ious": [_vp] * 6 + [_i] * 2 + [_vp] * 2,
-    "smin_build_targets": [_vp] * 5 + [_i] * 4 + [_vp] * 11,
+    "smin_build_targets": [_vp] * 5 + [_i] * 4 + [_vp] * 12,
     "smin_word_prep_fwd": [_vp] * 5 + [_i] * 5 + [_vp] * 5,
     "smin_word_prep_bwd_workspace_bytes": [_i] * 5,
     "smin_word_prep_bwd": [_vp] * 11 + [_i] * 5 + [_vp] * 3 + [_vp, _sz],

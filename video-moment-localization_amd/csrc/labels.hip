@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256)
 void build_targets_kernel(const float* __restrict__ times, const float* __restrict__ duration, const int* __restrict__ nfeats, const int* __restrict__ qlen,
                           int T, int L, int Nq, uint8_t* __restrict__ video_mask, uint8_t* __restrict__ query_mask, uint8_t* __restrict__ length_mask,
                           uint8_t* __restrict__ moment_mask, float* __restrict__ sm, uint8_t* __restrict__ ym, float* __restrict__ ss, uint8_t* __restrict__ ys,
-                          float* __restrict__ se, uint8_t* __restrict__ ye, uint8_t* __restrict__ ya)
+                          float* __restrict__ se, uint8_t* __restrict__ ye, uint8_t* __restrict__ ya, const float* __restrict__ two_sigma_sq)
 {
     const int b = blockIdx.y;
     const float ts = times[2 * b], te = times[2 * b + 1], dur = duration[b], Lf = (float)L;
@@ -35,7 +35,11 @@ void build_targets_kernel(const float* __restrict__ times, const float* __restri
     }
     if (k < L) {
         const float s_t = (float)k * dur / Lf, e_t = ((float)k + 1.0f) * dur / Lf;
-        const float sigma = (te - ts) / 5.0f, den = 2.0f * (sigma * sigma);
+        // dataset.py:116-119 forms sigma = (te - ts) / 5 and 2 sigma^2 in Python doubles from the annotation times and rounds once, at the
+        // tensor division: a caller that still has those doubles hands the rounded denominator in (two_sigma_sq); otherwise it is
+        // formed in double from the fp32 times (one rounding of each time instead of a chain of fp32 roundings)
+        const double sigma = ((double)te - (double)ts) / 5.0;
+        const float den = two_sigma_sq ? two_sigma_sq[b] : (float)(2.0 * (sigma * sigma));
         const float a = s_t - ts, c = e_t - te;
         const float vs = expf(-(a * a) / den), ve = expf(-(c * c) / den);
         const size_t o = (size_t)b * L + k;
@@ -52,12 +56,12 @@ void build_targets_kernel(const float* __restrict__ times, const float* __restri
 
 extern "C" int smin_build_targets(void* stream, const float* times, const float* duration, const int32_t* nfeats, const int32_t* qlen, int B, int T, int L, int Nq,
                                   uint8_t* video_mask, uint8_t* query_mask, uint8_t* length_mask, uint8_t* moment_mask, float* sm, uint8_t* ym,
-                                  float* ss, uint8_t* ys, float* se, uint8_t* ye, uint8_t* ya)
+                                  float* ss, uint8_t* ys, float* se, uint8_t* ye, uint8_t* ya, const float* two_sigma_sq)
 {
     SMIN_REQUIRE(B >= 0 && T >= 1 && L >= 1 && T % L == 0 && (query_mask == nullptr || (qlen != nullptr && Nq >= 1)));
     if (B == 0) return 0;
     hipLaunchKernelGGL(smin::build_targets_kernel, dim3(cdiv(L * L, 256), B), dim3(256), 0, (hipStream_t)stream, times, duration, nfeats, qlen, T, L, Nq,
-                       video_mask, query_mask, length_mask, moment_mask, sm, ym, ss, ys, se, ye, ya);
+                       video_mask, query_mask, length_mask, moment_mask, sm, ym, ss, ys, se, ye, ya, two_sigma_sq);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

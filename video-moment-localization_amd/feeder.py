@@ -26,6 +26,11 @@ def build_targets_hip(times, duration, nfeats, qlen, T, L, Nq, stream=None):
     f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     out = dict(video_mask=u8(B, T, 1), query_mask=u8(B, Nq, 1) if qlen is not None else None, length_mask=u8(B, L), moment_mask=u8(B, L, L),
                sm=f32(B, L, L), ym=u8(B, L, L), ss=f32(B, L), ys=u8(B, L), se=f32(B, L), ye=u8(B, L), ya=u8(B, L))
+    # annotation times that still carry their double precision: 2 sigma^2 in double, rounded once (dataset.py:116-119 does the same
+    # arithmetic in Python floats); fp32 times: the kernel forms it in double from what it is given
+    den = None
+    if times.dtype == torch.float64:
+        den = (2.0 * ((times[:, 1] - times[:, 0]) / 5.0) ** 2).float().contiguous()
     times, duration = times.float().contiguous(), duration.float().contiguous()
     nfeats = nfeats.to(torch.int32).contiguous()
     qlen32 = qlen.to(torch.int32).contiguous() if qlen is not None else None
@@ -33,7 +38,7 @@ def build_targets_hip(times, duration, nfeats, qlen, T, L, Nq, stream=None):
         s = _lib.stream() if stream is None else stream
         call("smin_build_targets", s, ptr(times), ptr(duration), ptr(nfeats), ptr(qlen32), B, T, L, Nq, ptr(out["video_mask"]), ptr(out["query_mask"]),
              ptr(out["length_mask"]), ptr(out["moment_mask"]), ptr(out["sm"]), ptr(out["ym"]), ptr(out["ss"]), ptr(out["ys"]), ptr(out["se"]),
-             ptr(out["ye"]), ptr(out["ya"]))
+             ptr(out["ye"]), ptr(out["ya"]), ptr(den))
     for k in ("length_mask", "moment_mask", "ym", "ys", "ye", "ya"):
         out[k] = out[k].view(torch.bool)                      # same bytes; the reference's tensors are BoolTensors
     if qlen is None:

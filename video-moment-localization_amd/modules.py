@@ -406,6 +406,17 @@ class SMIN(nn.Module):
         self.max_query_length, self.lstm_hidden_size, self.device = max_query_length, lstm_hidden_size, device
         if D != 2 * lstm_hidden_size:
             raise ValueError("SMIN needs D == 2 * lstm_hidden_size (reference models.py:62,81)")
+        # shape limits of the HIP kernels behind this module (the reference has none): named here, not as a bare
+        # "argument rejected at csrc line N" from the middle of a forward pass
+        limits = [(T % L == 0, f"L | T (T={T}, L={L}): the reference's AvgPool1d gives {T // max(T // L, 1)} != L boundary rows otherwise (SURVEY 8a-2)"),
+                  (2 <= C <= 4, f"2 <= C <= 4 clips per moment (C={C}): csrc/content_attn.hip keeps the clips of a cell in one lane quad"),
+                  (D % 4 == 0, f"D % 4 == 0 (D={D}): 16-byte row segments everywhere"),
+                  (dl % 16 == 0 and 16 <= dl <= 128, f"dl a multiple of 16 in [16, 128] (dl={dl}): csrc/content_attn.hip tiles the attention rows in 16-feature blocks, csrc/word_prep.hip holds dl <= 128"),
+                  (1 <= max_query_length <= 32, f"max_query_length <= 32 (got {max_query_length}): the word-side kernels keep a query in 32 LDS slots"),
+                  (num_smi_layers >= 1, f"num_smi_layers >= 1 (got {num_smi_layers})")]
+        bad = [msg for ok, msg in limits if not ok]
+        if bad:
+            raise ValueError("SMIN: outside the limits of the HIP kernels -- needs " + "; ".join(bad))
         self.backbone = Backbone(T, D, input_video_dim, max_query_length, lstm_hidden_size, device)
         self.pgm = ProposalGeneration(T, L, C, device)
         self.smis = nn.ModuleList([SMI(D, dl) for _ in range(num_smi_layers)])
