@@ -366,6 +366,12 @@ def main():
     if os.path.exists(pmc_path) and args.workload == "activitynet_t256" and B == cfg[-1] and args.gemm == "f32":
         try:                                                # PMC traffic (rocprofv3 --pmc, gfx950 corrections) of exactly this workload
             pmc = json.load(open(pmc_path))
+            import hashlib                                   # ... measured on the GEMM engine as built from these sources: stale -> no traffic figure
+            csrc = os.path.join(ROOT, "video-moment-localization_amd", "csrc")
+            stamp = pmc.get("sources_sha256") or {}
+            if not stamp or any(hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() != h for f, h in stamp.items()):
+                pmc = {"stale": "profiles/pmc_moment.json was measured on other gemm.h / moment_unit.hip sources (or carries no stamp): traffic omitted; "
+                                "regenerate with profiles/run_pmc.sh + profiles/make_pmc_moment.py"}
         except Exception:
             pmc = {}
     roofline = None
@@ -375,6 +381,8 @@ def main():
                     "frac": g["frac"], "traffic": pmc.get("moment_fwd", {}).get("hbm_bytes_per_launch"), "avg_launch_ms": g["avg_launch_ms"],
                     "launches_timed": g["launches_timed"], "flops_per_launch": mu_flops, "valid_cells_per_launch": n_valid,
                     "algorithmic_bytes_per_launch": 4.0 * n_valid * 4 * D}
+        if "stale" in pmc:
+            roofline["traffic_note"] = pmc["stale"]
         if args.gemm == "bf16":                                # bf16 products run at 16x the fp32 matrix rate: the contraction is bound by its operand traffic
             ach = roofline["algorithmic_bytes_per_launch"] / (g["avg_launch_ms"] * 1e-3) / 1e9
             roofline.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,

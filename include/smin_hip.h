@@ -332,6 +332,11 @@ int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, cons
                           const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
 
+/* The recurrences above run, for H a multiple of 32, as clusters of workgroups that keep W_hh in LDS and exchange h / dh through
+ * tagged granules in global memory (csrc/bilstm_cluster.hip); every poll there is bounded.  Returns 1 once a poll has expired since
+ * the last call (the launch that hit it produced wrong values), 0 otherwise; clears the word.  Synchronises the device. */
+int smin_lstm_cluster_error(void);
+
 /* ---- packed valid-cell layout from a (B, L, L) mask (uint8 / bool, non-zero = valid).  all_cells = 0: list the valid
  * cells (m = 1); 1: list every (b, i, j) with m = mask.  cells [N][4] = {b, i, j, m} sorted by (b, i, j); row_ptr
  * [B*L + 1]; cellmap [B][L][L] = cell id or -1.  The caller sizes cells from the count of listed cells. */

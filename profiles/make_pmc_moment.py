@@ -25,5 +25,10 @@ for tag, (a, b) in pick.items():
         if v.get("avg_ns_under_pmc"):
             d["clock_ghz"] = v["GRBM_GUI_ACTIVE"] / 8 / v["avg_ns_under_pmc"]
     out[tag] = d
+# the counters describe the GEMM engine as built from these sources: bench.py drops `traffic` when they have changed since
+import hashlib
+import os
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-moment-localization_amd", "csrc")
+out["sources_sha256"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in ("gemm.h", "moment_unit.hip")}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -19,6 +19,12 @@
 
 namespace smin {
 
+// the same recurrences with W_hh resident in LDS, split over clusters of workgroups (bilstm_cluster.hip); H a multiple of 32
+bool bilstm_cluster_ok(int B, int Nq, int H);
+int launch_bilstm_cluster_fwd(hipStream_t st, float* G, const float* W4, const int* len, int B, int Nq, int H, float* Hout, float* Cs);
+int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G, const float* Cs, const float* Whh, const int* len, int B, int Nq, int H,
+                              float* dG);
+
 constexpr int LSTM_BS = 4;          // samples per workgroup
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -290,6 +296,7 @@ extern "C" int smin_bilstm_layer_fwd(void* stream, const float* X, const float* 
     SMIN_REQUIRE(In % 4 == 0 && H % 4 == 0 && H >= 4 && H <= 256 && B >= 1 && Nq >= 1);
     int rc = launch_gemm_nt(st, PlainMat{X, In}, PlainMat{Wih_cat, In}, EpBiasRows{bias_cat, G}, B * Nq, 8 * H, In);
     if (rc) return rc;
+    if (bilstm_cluster_ok(B, Nq, H)) return launch_bilstm_cluster_fwd(st, G, W4, len, B, Nq, H, Hout, Cs);
     const int Hp = cdiv(H, 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)H * LSTM_BS + (size_t)16 * LSTM_BS * Hp);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -354,8 +361,13 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
     SMIN_REQUIRE(dHout != nullptr || dWih_cat != nullptr);
     int rc;
     if (dHout) {                                                       // inputs half: the recurrence (gate gradients stay in ws), dX
-        hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
-        SMIN_LAUNCH_CHECK();
+        if (bilstm_cluster_ok(B, Nq, H)) {
+            rc = launch_bilstm_cluster_bwd(st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(cdiv(B, LSTM_BS), 2), dim3(4 * Hp), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, dG);
+            SMIN_LAUNCH_CHECK();
+        }
         if (dX) {
             rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
             if (rc) return rc;

@@ -1,0 +1,351 @@
+// The LSTM recurrence with W_hh resident on the chip (reference models.py:38-64, the nn.LSTM of the query encoder).
+//
+// bilstm.hip runs the recurrence of a (sample group, direction) in ONE workgroup that streams the whole W_hh (1 MB at H = 256)
+// from L2 every time step: ~11 us per step at one CU's L2 bandwidth, 0.22 ms per layer and pass on 32 of the 256 CUs, four
+// times on the critical path of a train step.  Here a *cluster* of P = H / 32 workgroups shares a (sample group, direction):
+// workgroup p owns 32 hidden units -- their 4 x 32 gate rows of W_hh, 128 KB, stay in its LDS for the whole launch -- and the
+// workgroups exchange what the next step needs through global memory:
+//   forward   every workgroup needs all of h_t [H][4 samples]: each publishes its 32 x 4 values, all gather the rest;
+//   backward  dh_{t-1}[u'] = sum_j dg_t[j] W_hh[j][u']: each workgroup contracts its own 128 gate rows against all H columns and
+//             sends workgroup p' the partial sums of p's units; the owner adds the P partial sums in workgroup order (fixed: deterministic).
+// Hand-off form (MI355X_MICROARCH.md, "Valid forms", R2): data-tagged 8-byte granules {value, step tag}, each written by ONE
+// relaxed agent-scope atomic store (global_store_dwordx2 sc1) and polled with relaxed agent-scope atomic loads (sc1: served past
+// the L1) -- no flags, no fences, no L2 write-back.  Two granule buffers alternate by step parity: a workgroup writes step s + 2
+// only after it has read every other workgroup's step s + 1, which they publish only after reading all of step s -- so the
+// buffer it overwrites has been read by everyone.  The exchange buffer is cleared by a memset node ahead of each launch (tags
+// start at 1), so replays of a captured step see no stale tags.  Every poll is bounded: on expiry an error word is set and the
+// launch finishes with wrong values instead of hanging.
+// Residency: the grid never exceeds one workgroup per CU (clusters loop over their sample groups), so every workgroup of a
+// cluster becomes resident without waiting for another workgroup of this launch to exit.
+#include "gemm.h"
+#include "smin_hip.h"
+#include <stdlib.h>
+
+namespace smin {
+
+constexpr int CL_BS = 4;            // samples per cluster pass
+constexpr int CL_U = 32;            // hidden units per workgroup
+constexpr int CL_KQ = 8;            // forward: contraction split (threads = CL_U * CL_KQ = 256)
+constexpr unsigned CL_SPIN = 1u << 22;
+
+__device__ unsigned int g_lstm_cluster_error;
+
+__device__ __forceinline__ float csigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ void granule_store(unsigned long long* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits for the granule to carry `tag`; returns its value (bounded: see the header)
+__device__ __forceinline__ float granule_wait(const unsigned long long* p, unsigned tag) {
+    unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((unsigned)(g >> 32) != tag) {
+        if (++spins > CL_SPIN) { g_lstm_cluster_error = 1u; break; }
+        __builtin_amdgcn_s_sleep(1);
+        g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __uint_as_float((unsigned)g);
+}
+
+// workgroup id -> (cluster, member): the P members of a cluster are ids with the same id % 8, i.e. one XCD under the observed
+// round-robin placement (speed only: the exchange is then served by one L2)
+__device__ __forceinline__ void cluster_of(int id, int P, int& cluster, int& member) {
+    const int xcd = id & 7, slot = id >> 3;
+    cluster = (slot / P) * 8 + xcd;
+    member = slot % P;
+}
+
+// G [B][Nq][2][4H] in: input projections + biases; out: gate activations.  W4 [2][H][H][4] (W4[d][k][u][g] = W_hh_d[gH + u][k]).
+// xch: [nclus][2 parities][H][CL_BS] granules.  grid = nclus_pad * P workgroups of 256 threads; ngroups = ceil(B / CL_BS) * 2 (group, direction) passes
+// are dealt round-robin over the nclus clusters.
+__global__ __launch_bounds__(256)
+void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ W4, const int* __restrict__ len, int B, int Nq, int H, int P, int nclus,
+                               float* __restrict__ Hout, float* __restrict__ Cs, unsigned long long* __restrict__ xch)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BS = CL_BS, U = CL_U, KQ = CL_KQ;
+    float4* Wl = reinterpret_cast<float4*>(lds);                   // [H][U] float4 = the four gates of (k, unit)
+    float* hs = lds + (size_t)H * U * 4;                           // [H][BS]
+    float* part = hs + (size_t)H * BS;                             // [KQ][4 g][BS][U]
+    int cluster, p;
+    cluster_of(blockIdx.x, P, cluster, p);
+    if (cluster >= nclus) return;
+    const int tid = threadIdx.x, ul = tid % U, kq = tid / U;
+    const int u0 = p * U, u = u0 + ul, H4 = 4 * H, kn = H / KQ, k0 = kq * kn;
+    const int ngroups = ((B + BS - 1) / BS) * 2;
+    unsigned long long* X = xch + (size_t)cluster * 2 * H * BS;
+    unsigned tagbase = 0;                                          // tags grow over the passes of a cluster: no clearing between passes
+
+    for (int grp = cluster; grp < ngroups; grp += nclus) {
+        const int d = grp & 1, b0 = (grp >> 1) * BS;
+        __syncthreads();                                           // the previous pass is done with the LDS images
+        for (int e = tid; e < H * U; e += 256) {                   // this workgroup's W_hh slice: W4[d][k][u0 .. u0+U)
+            const int k = e / U, x = e % U;
+            Wl[e] = *reinterpret_cast<const float4*>(W4 + (((size_t)d * H + k) * H + u0 + x) * 4);
+        }
+        for (int e = tid; e < H * BS; e += 256) hs[e] = 0.f;
+        const int bme = b0 + kq;                                   // finishing threads: kq < BS -> sample kq of the group
+        const bool fin = kq < BS;
+        const int L = (fin && bme < B) ? min(len[bme], Nq) : 0;
+        float c = 0.f;
+        __syncthreads();
+        for (int s = 0; s < Nq; ++s) {
+            const bool act = s < L;
+            const int pos = d == 0 ? s : L - 1 - s;
+            const size_t row = (size_t)(fin && bme < B ? bme : 0) * Nq + (act ? pos : 0);
+            float gx[4] = {0.f, 0.f, 0.f, 0.f};
+            if (act) {
+                const float* g = G + (row * 2 + d) * H4 + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gx[q] = g[q * H];
+            }
+            float a[BS][4];
+#pragma unroll
+            for (int b = 0; b < BS; ++b) { a[b][0] = 0.f; a[b][1] = 0.f; a[b][2] = 0.f; a[b][3] = 0.f; }
+#pragma unroll 8
+            for (int k = 0; k < kn; ++k) {
+                const float4 w4 = Wl[(k0 + k) * U + ul];
+                const float4 h4 = *reinterpret_cast<const float4*>(hs + (k0 + k) * BS);
+                const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int b = 0; b < BS; ++b) {
+                    a[b][0] = fmaf(hv[b], w4.x, a[b][0]); a[b][1] = fmaf(hv[b], w4.y, a[b][1]);
+                    a[b][2] = fmaf(hv[b], w4.z, a[b][2]); a[b][3] = fmaf(hv[b], w4.w, a[b][3]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part[((kq * 4 + q) * BS + b) * U + ul] = a[b][q];
+            __syncthreads();                                        // partial sums visible; everyone is done reading hs
+            // the last step's h feeds nothing -- but unless this is the cluster's last pass the exchange still runs: it is what keeps a fast
+            // workgroup from overwriting, in its next pass, granules a slow one has not read yet (see the header)
+            const bool xchg = P > 1 && (s + 1 < Nq || grp + nclus < ngroups);
+            const unsigned gs = tagbase + (unsigned)s, tag = gs + 1u;
+            unsigned long long* Xs = X + (size_t)(gs & 1u) * H * BS;
+            if (fin) {
+                float hn = 0.f;
+                if (act) {
+                    float z[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KQ; ++k) sum += part[((k * 4 + q) * BS + kq) * U + ul];
+                        z[q] = gx[q] + sum;
+                    }
+                    const float ig = csigm(z[0]), fg = csigm(z[1]), gg = tanhf(z[2]), og = csigm(z[3]);
+                    c = fmaf(fg, c, ig * gg);
+                    hn = og * tanhf(c);
+                    float* g = G + (row * 2 + d) * H4 + u;
+                    g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+                    Cs[(row * 2 + d) * H + u] = c;
+                    Hout[row * 2 * H + d * H + u] = hn;
+                } else if (bme < B) {
+                    Hout[((size_t)bme * Nq + s) * 2 * H + d * H + u] = 0.f;        // padded position s >= len
+                }
+                hs[u * BS + kq] = hn;                               // own units: straight into the local image
+                if (xchg) granule_store(Xs + (size_t)u * BS + kq, hn, tag);
+            }
+            if (xchg) {                                             // gather the other workgroups' units
+                for (int e = tid; e < H * BS; e += 256) {
+                    const int uu = e / BS;
+                    if (uu / U != p) hs[e] = granule_wait(Xs + e, tag);
+                }
+            }
+            __syncthreads();
+        }
+        tagbase += (unsigned)Nq;
+    }
+}
+
+// Backward recurrence.  Whh [2][4H][H] as nn.LSTM stores it; dG [B][Nq][2][4H] out (zero at padded positions).
+// xch: [nclus][2 parities][P dest][P src][U][CL_BS] granules.  256 threads: gate phase thread (b, ul) = (tid / U, tid % U) for tid < 128;
+// contraction phase thread u' = tid (+ 256 ..) over the workgroup's 128 gate rows.
+__global__ __launch_bounds__(256)
+void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __restrict__ G, const float* __restrict__ Cs, const float* __restrict__ Whh,
+                               const int* __restrict__ len, int B, int Nq, int H, int P, int nclus, float* __restrict__ dG,
+                               unsigned long long* __restrict__ xch)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BS = CL_BS, U = CL_U;
+    float* Wt = lds;                                               // [4U][H]: row g*U + ul = W_hh[g H + u0 + ul][:]
+    float* dgs = lds + (size_t)4 * U * H;                          // [4U][BS]
+    float* own = dgs + (size_t)4 * U * BS;                         // [U][BS] this workgroup's partial sums for its own units
+    int cluster, p;
+    cluster_of(blockIdx.x, P, cluster, p);
+    if (cluster >= nclus) return;
+    const int tid = threadIdx.x, ul = tid % U, bq = tid / U;
+    const int u0 = p * U, u = u0 + ul, H4 = 4 * H;
+    const int ngroups = ((B + BS - 1) / BS) * 2;
+    unsigned long long* X = xch + (size_t)cluster * 2 * P * P * U * BS;
+    unsigned tagbase = 0;
+
+    for (int grp = cluster; grp < ngroups; grp += nclus) {
+        const int d = grp & 1, b0 = (grp >> 1) * BS;
+        __syncthreads();
+        for (int e = tid; e < 4 * U * (H / 4); e += 256) {         // the slice, float4 along u'
+            const int j = e / (H / 4), c4 = e % (H / 4), g = j / U, x = j % U;
+            *reinterpret_cast<float4*>(Wt + (size_t)j * H + 4 * c4) =
+                *reinterpret_cast<const float4*>(Whh + ((size_t)d * H4 + (size_t)g * H + u0 + x) * H + 4 * c4);
+        }
+        const bool fin = bq < BS;
+        const int bme = b0 + bq;
+        const int L = (fin && bme < B) ? min(len[bme], Nq) : 0;
+        float dhn = 0.f, dcn = 0.f;
+        __syncthreads();
+        int it = 0;
+        for (int s = Nq - 1; s >= 0; --s, ++it) {
+            const bool act = s < L;
+            if (fin) {
+                float dg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (act) {
+                    const int pos = d == 0 ? s : L - 1 - s;
+                    const size_t row = (size_t)bme * Nq + pos;
+                    const float* g = G + (row * 2 + d) * H4 + u;
+                    const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+                    const float ct = Cs[(row * 2 + d) * H + u];
+                    const float cp = s > 0 ? Cs[(((size_t)bme * Nq + (d == 0 ? pos - 1 : pos + 1)) * 2 + d) * H + u] : 0.f;
+                    const float dh = dHout[row * 2 * H + d * H + u] + dhn;
+                    const float tc = tanhf(ct);
+                    const float dc = fmaf(dh * og, 1.0f - tc * tc, dcn);
+                    dg[0] = dc * gg * ig * (1.0f - ig);
+                    dg[1] = dc * cp * fg * (1.0f - fg);
+                    dg[2] = dc * ig * (1.0f - gg * gg);
+                    dg[3] = dh * tc * og * (1.0f - og);
+                    dcn = dc * fg;
+                    float* o = dG + (row * 2 + d) * H4 + u;
+                    o[0] = dg[0]; o[H] = dg[1]; o[2 * H] = dg[2]; o[3 * H] = dg[3];
+                } else if (bme < B) {
+                    float* o = dG + ((((size_t)bme * Nq + s) * 2 + d) * H4) + u;   // padded position s >= len
+                    o[0] = 0.f; o[H] = 0.f; o[2 * H] = 0.f; o[3 * H] = 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dgs[(size_t)(q * U + ul) * BS + bq] = dg[q];
+            }
+            __syncthreads();
+            if (s == 0 && !(P > 1 && grp + nclus < ngroups)) break;   // dh of the step before the first feeds nothing (exchange kept between passes, as in the forward)
+            const unsigned gs = tagbase + (unsigned)it, tag = gs + 1u;
+            unsigned long long* Xs = X + (size_t)(gs & 1u) * P * P * U * BS;
+            for (int up = tid; up < H; up += 256) {                 // partial dh[b][u'] over this workgroup's 4U gate rows
+                float a[BS] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int j = 0; j < 4 * U; ++j) {
+                    const float w = Wt[(size_t)j * H + up];
+                    const float4 g4 = *reinterpret_cast<const float4*>(dgs + (size_t)j * BS);
+                    a[0] = fmaf(g4.x, w, a[0]); a[1] = fmaf(g4.y, w, a[1]); a[2] = fmaf(g4.z, w, a[2]); a[3] = fmaf(g4.w, w, a[3]);
+                }
+                const int dest = up / U, x = up % U;
+                if (dest == p) {
+#pragma unroll
+                    for (int b = 0; b < BS; ++b) own[x * BS + b] = a[b];
+                } else {
+                    unsigned long long* o = Xs + (((size_t)dest * P + p) * U + x) * BS;
+#pragma unroll
+                    for (int b = 0; b < BS; ++b) granule_store(o + b, a[b], tag);
+                }
+            }
+            __syncthreads();                                        // own[] visible; dgs free for the next step
+            if (fin) {                                              // the owner adds the P partial sums in workgroup order
+                float sum = 0.f;
+                for (int src = 0; src < P; ++src)
+                    sum += src == p ? own[ul * BS + bq] : granule_wait(Xs + (((size_t)p * P + src) * U + ul) * BS + bq, tag);
+                dhn = sum;
+            }
+            // (own[] is rewritten only after the next step's first barrier)
+        }
+        tagbase += (unsigned)Nq;
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+static int cl_num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// persistent exchange buffer per device (grown on demand; cleared ahead of every launch by the caller below)
+static unsigned long long* cl_exchange(size_t granules)
+{
+    static unsigned long long* buf[16] = {nullptr};
+    static size_t cap[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (cap[dev] < granules) {
+        if (buf[dev]) (void)hipFree(buf[dev]);
+        buf[dev] = nullptr; cap[dev] = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&buf[dev]), granules * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        cap[dev] = granules;
+    }
+    return buf[dev];
+}
+
+bool bilstm_cluster_ok(int B, int Nq, int H)
+{
+    (void)B;
+    return H % CL_U == 0 && H >= CL_U && H <= 256 && Nq < (1 << 20) && !getenv("SMIN_LSTM_STREAMED");
+}
+static void cl_geometry(int B, int H, int& P, int& nclus, int& grid)
+{
+    P = H / CL_U;
+    const int ngroups = cdiv(B, CL_BS) * 2;
+    int maxclus = cl_num_cus() / P;                                  // never more than one workgroup per CU: see the header
+    if (maxclus < 1) maxclus = 1;
+    nclus = ngroups < maxclus ? ngroups : maxclus;
+    grid = cdiv(nclus, 8) * 8 * P;                                   // cluster_of deals ids over 8 XCD classes
+}
+
+int launch_bilstm_cluster_fwd(hipStream_t st, float* G, const float* W4, const int* len, int B, int Nq, int H, float* Hout, float* Cs)
+{
+    int P, nclus, grid;
+    cl_geometry(B, H, P, nclus, grid);
+    const size_t lds = sizeof(float) * ((size_t)H * CL_U * 4 + (size_t)H * CL_BS + (size_t)CL_KQ * 4 * CL_BS * CL_U);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_cluster_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+        attr = true;
+    }
+    const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * H * CL_BS;
+    unsigned long long* xch = cl_exchange(gran > ((size_t)1 << 16) ? gran : ((size_t)1 << 16));
+    if (!xch) return -2;
+    if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
+    hipLaunchKernelGGL(bilstm_cluster_fwd_kernel, dim3(grid), dim3(256), lds, st, G, W4, len, B, Nq, H, P, nclus, Hout, Cs, xch);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G, const float* Cs, const float* Whh, const int* len, int B, int Nq, int H,
+                              float* dG)
+{
+    int P, nclus, grid;
+    cl_geometry(B, H, P, nclus, grid);
+    const size_t lds = sizeof(float) * ((size_t)4 * CL_U * H + (size_t)4 * CL_U * CL_BS + (size_t)CL_U * CL_BS);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_cluster_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+        attr = true;
+    }
+    const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * P * P * CL_U * CL_BS;
+    unsigned long long* xch = cl_exchange(gran > ((size_t)1 << 16) ? gran : ((size_t)1 << 16));
+    if (!xch) return -2;
+    if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
+    hipLaunchKernelGGL(bilstm_cluster_bwd_kernel, dim3(grid), dim3(256), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, P, nclus, dG, xch);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace smin
+
+// non-zero once a bounded poll of the cluster recurrence has expired (the results of that launch are wrong); clears the word
+extern "C" int smin_lstm_cluster_error(void)
+{
+    unsigned int v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(smin::g_lstm_cluster_error), sizeof(v)) != hipSuccess) return -1;
+    if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(smin::g_lstm_cluster_error), &z, sizeof(z));
+    return (int)v;
+}
