@@ -1289,6 +1289,9 @@ def test_standalone_attention_classes_against_oracle(dev):
             assert rel_err(got.detach().cpu(), want.detach()) < 1e-5, cls.__name__
             eq, ek = rel_err(q1.grad.cpu(), q0.grad), rel_err(k1.grad.cpu(), k0.grad)
             assert eq < 1e-4 and ek < 1e-4, (cls.__name__, B, eq, ek)
+            # (W_k.bias shifts every score of a row equally: softmax-invariant, its true gradient is zero and what is computed is
+            #  rounding noise -- held to the scale of the whole gradient)
+            gmax = max(sd["x." + name].grad.abs().max().item() for name, _ in mod.named_parameters())
             for name, p in mod.named_parameters():
                 ref = sd["x." + name].grad
-                assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6, (cls.__name__, name)
+                assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5 * gmax, (cls.__name__, name)
