@@ -47,6 +47,29 @@ __device__ __forceinline__ float granule_wait(const unsigned long long* p, unsig
     return __uint_as_float((unsigned)g);
 }
 
+// N granules at once: every load is in flight before the first tag is looked at (N dependent round trips otherwise: the owner of a
+// unit waited for its P - 1 partial sums one after the other, ~1 us each)
+template <int N>
+__device__ __forceinline__ void granules_wait(float (&out)[N], const unsigned long long* const (&p)[N], const bool (&want)[N], unsigned tag) {
+    unsigned long long g[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = want[i] ? __hip_atomic_load(p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && (unsigned)(g[i] >> 32) == tag;
+        if (all) break;
+        if (++spins > CL_SPIN) { g_lstm_cluster_error = 1u; break; }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((unsigned)(g[i] >> 32) != tag) g[i] = __hip_atomic_load(p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __uint_as_float((unsigned)g[i]);
+}
+
 // workgroup id -> (cluster, member): the P members of a cluster are ids with the same id % 8, i.e. one XCD under the observed
 // round-robin placement (speed only: the exchange is then served by one L2)
 __device__ __forceinline__ void cluster_of(int id, int P, int& cluster, int& member) {
@@ -147,11 +170,19 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
                 hs[u * BS + kq] = hn;                               // own units: straight into the local image
                 if (xchg) granule_store(Xs + (size_t)u * BS + kq, hn, tag);
             }
-            if (xchg) {                                             // gather the other workgroups' units
-                for (int e = tid; e < H * BS; e += 256) {
-                    const int uu = e / BS;
-                    if (uu / U != p) hs[e] = granule_wait(Xs + e, tag);
+            if (xchg) {                                             // gather the other workgroups' units (H * BS <= 1024 granules: four per thread)
+                float v[4];
+                const unsigned long long* ptr[4];
+                bool want[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = tid + 256 * i;
+                    want[i] = e < H * BS && (e / BS) / U != p;
+                    ptr[i] = Xs + (want[i] ? e : 0);
                 }
+                granules_wait<4>(v, ptr, want, tag);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (want[i]) hs[tid + 256 * i] = v[i];
             }
             __syncthreads();
         }
@@ -193,20 +224,37 @@ void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __r
         const int bme = b0 + bq;
         const int L = (fin && bme < B) ? min(len[bme], Nq) : 0;
         float dhn = 0.f, dcn = 0.f;
+        // the gate phase's operands (saved gates, cell states, the output gradient) do not depend on the recurrence: those of step
+        // s - 1 are requested while step s contracts, so no step starts with an L2 round trip
+        struct GateIn { float ig, fg, gg, og, ct, cp, dho; };
+        auto fetch = [&](int s2) {
+            GateIn r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fin && s2 >= 0 && s2 < L) {
+                const int pos = d == 0 ? s2 : L - 1 - s2;
+                const size_t row = (size_t)bme * Nq + pos;
+                const float* g = G + (row * 2 + d) * H4 + u;
+                r.ig = g[0]; r.fg = g[H]; r.gg = g[2 * H]; r.og = g[3 * H];
+                r.ct = Cs[(row * 2 + d) * H + u];
+                r.cp = s2 > 0 ? Cs[(((size_t)bme * Nq + (d == 0 ? pos - 1 : pos + 1)) * 2 + d) * H + u] : 0.f;
+                r.dho = dHout[row * 2 * H + d * H + u];
+            }
+            return r;
+        };
+        GateIn cur = fetch(Nq - 1);
         __syncthreads();
         int it = 0;
         for (int s = Nq - 1; s >= 0; --s, ++it) {
             const bool act = s < L;
+            const GateIn nxt = fetch(s - 1);
             if (fin) {
                 float dg[4] = {0.f, 0.f, 0.f, 0.f};
                 if (act) {
                     const int pos = d == 0 ? s : L - 1 - s;
                     const size_t row = (size_t)bme * Nq + pos;
-                    const float* g = G + (row * 2 + d) * H4 + u;
-                    const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
-                    const float ct = Cs[(row * 2 + d) * H + u];
-                    const float cp = s > 0 ? Cs[(((size_t)bme * Nq + (d == 0 ? pos - 1 : pos + 1)) * 2 + d) * H + u] : 0.f;
-                    const float dh = dHout[row * 2 * H + d * H + u] + dhn;
+                    const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og;
+                    const float ct = cur.ct;
+                    const float cp = cur.cp;
+                    const float dh = cur.dho + dhn;
                     const float tc = tanhf(ct);
                     const float dc = fmaf(dh * og, 1.0f - tc * tc, dcn);
                     dg[0] = dc * gg * ig * (1.0f - ig);
@@ -246,12 +294,22 @@ void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __r
                 }
             }
             __syncthreads();                                        // own[] visible; dgs free for the next step
-            if (fin) {                                              // the owner adds the P partial sums in workgroup order
+            if (fin) {                                              // the owner adds the P partial sums in workgroup order (P <= 8)
+                float v[8];
+                const unsigned long long* ptr[8];
+                bool want[8];
+#pragma unroll
+                for (int src = 0; src < 8; ++src) {
+                    want[src] = src < P && src != p;
+                    ptr[src] = Xs + (((size_t)p * P + (want[src] ? src : 0)) * U + ul) * BS + bq;
+                }
+                granules_wait<8>(v, ptr, want, tag);
                 float sum = 0.f;
-                for (int src = 0; src < P; ++src)
-                    sum += src == p ? own[ul * BS + bq] : granule_wait(Xs + (((size_t)p * P + src) * U + ul) * BS + bq, tag);
+#pragma unroll
+                for (int src = 0; src < 8; ++src) if (src < P) sum += src == p ? own[ul * BS + bq] : v[src];
                 dhn = sum;
             }
+            cur = nxt;
             // (own[] is rewritten only after the next step's first barrier)
         }
         tagbase += (unsigned)Nq;
