@@ -245,6 +245,8 @@ def main():
         prof = lib.prof_read()
     elapsed = dp.max_over_ranks(elapsed, dev)                  # slowest rank defines the step
     # the same K steps without the optimizer: SURVEY 8d defines the metric on zero_grad + fwd + loss + bwd (+ all-reduce)
+    if captured:
+        step(with_opt=False)                                  # (captures that variant's graph outside the timed region)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
