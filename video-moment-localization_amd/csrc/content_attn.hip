@@ -319,7 +319,7 @@ __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&c
                                                  int lane, ATT att)
 {
     const int kg = lane >> 4;
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4v Z = {0.f, 0.f, 0.f, 0.f}, Zb = {0.f, 0.f, 0.f, 0.f};  // q q^T over the clips of a cell on the 4x4x1 MFMA (quad_neighbour_order)
 #pragma unroll
     for (int j = 0; j < DL / 16; ++j) {
         const f32x4v acc = att(j);
@@ -328,11 +328,13 @@ __device__ __forceinline__ void clip_attention16(float (&Ao)[4], const float (&c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float qv = ch[j][q] * (acc[q] + shv[q]);
-            z[0] = fmaf(qv, qv, z[0]);
-            fmac_nb3(z[1], z[2], z[3], qv, qv, qv, qv);
+            if (q & 1) Zb = mfma4(qv, qv, Zb); else Z = mfma4(qv, qv, Z);
         }
         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
+    Z += Zb;
+    float z[4];
+    quad_neighbour_order(z, Z, lane);
     clip_softmax(Ao, z, g, scale);
 }
 
@@ -451,7 +453,7 @@ static size_t fwd_lds_bytes() { return sizeof(float) * (size_t)(32 * (DL + 4) + 
 // EXACT: dl == DL and C == 4 (every shipped configuration): row strides, feature clamps and clip predicates are constants --
 // fewer address instructions and far fewer scalar registers (the general form keeps a clamped offset and a predicate per block)
 template <int DL, int WS, int ROWS, bool MEAN, bool EXACT>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, 4)
 void content_attn_fwd_kernel(const float* __restrict__ chat, const int* __restrict__ cells, const int* __restrict__ row_ptr, int L, int C,
                              const float* __restrict__ Mq, const float* __restrict__ uq, const float* __restrict__ what,
                              const float* __restrict__ shat, const float* __restrict__ qmask,
@@ -966,7 +968,8 @@ static int fwd_t(hipStream_t st, const float* chat, const int* cells, const int*
                  float* cc_rows, float* cc_mean, int dl, int Nq, bool rows_bf16)
 {
     (void)B;
-    const int cpr = range_cells(N, 3 * attn_num_cus(), 16);      // three 256-thread workgroups per CU (<= 168 registers, 36 KB of LDS each)
+    static const int wgs_per_cu = getenv("SMIN_ATTN_FWD_WGS") ? atoi(getenv("SMIN_ATTN_FWD_WGS")) : 3;
+    const int cpr = range_cells(N, wgs_per_cu * attn_num_cus(), 16);      // three 256-thread workgroups per CU (118 registers, 36 KB of LDS each; four measured no faster: the launch is bound by HBM)
     const dim3 grid(cdiv(N, cpr));
     const size_t lds = fwd_lds_bytes<DL>();
     const float scale = 1.0f / sqrtf((float)dl);

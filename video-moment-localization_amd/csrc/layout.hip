@@ -24,7 +24,19 @@ void layout_rows_kernel(const uint8_t* __restrict__ mask, int rows, int L, int a
             if (all_cells) c = L;
             else {
                 const uint8_t* m = mask + (size_t)r * L;
-                for (int j = 0; j < L; ++j) c += m[j] != 0;
+                if ((L & 15) == 0) {                                // 16 mask bytes per load (rows are L bytes apart: 16-byte aligned with the base)
+                    for (int j = 0; j < L; j += 16) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(m + j);
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {               // bytes are 0 / non-zero: count the non-zero ones
+                            const unsigned nz = (w[q] | (w[q] >> 4)) & 0x0f0f0f0fu, t2 = (nz | (nz >> 2)) & 0x03030303u, t1 = (t2 | (t2 >> 1)) & 0x01010101u;
+                            c += __popc(t1);
+                        }
+                    }
+                } else {
+                    for (int j = 0; j < L; ++j) c += m[j] != 0;
+                }
             }
         }
         part[t] = c;
