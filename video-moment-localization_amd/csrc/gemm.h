@@ -925,6 +925,8 @@ static inline int tn_splits(int Mrows, int I, int J)
     return s;
 }
 
+int tn_extra_lds();                                    // util.hip: bytes of unused dynamic LDS per weight-gradient workgroup (occupancy cap)
+
 template <class AM, class BM_>
 static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, float* slab, float* bias_slab,
                                  int Mrows, int I, int J, int splits)
@@ -949,11 +951,14 @@ static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, fl
         SMIN_LAUNCH_CHECK();
         return 0;
     }
+    // weight gradients run on a low-priority stream beside the step's critical chain: unused dynamic LDS caps how many of
+    // their workgroups a CU takes, so that the chain's kernels find registers free (see tn_extra_lds)
+    const size_t xl = (size_t)tn_extra_lds();
     if (bias_slab)
-        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, true>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, true>), grid, dim3(256), xl, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
                            tiles_i, tiles_j, splits);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, false>), grid, dim3(256), 0, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
+        hipLaunchKernelGGL((gemm_tn_kernel<AM, BM_, false>), grid, dim3(256), xl, st, am, bm, slab, bias_slab, Mrows, I, J, rows_per_split,
                            tiles_i, tiles_j, splits);
     SMIN_LAUNCH_CHECK();
     return 0;

@@ -1,12 +1,30 @@
 // Library identity, workspace sizing, slab reduction, dense<->packed layout helpers, stand-alone GEMM.
 #include "gemm.h"
 #include "smin_hip.h"
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
 namespace smin {
 
 int g_gemm_mode = 0;
+
+// see launch_gemm_tn (gemm.h).  The exact-fp32 weight-gradient kernel is built for three workgroups per CU (32 KB of LDS, 168
+// registers: 3 x 168 of a SIMD's 512).  In the train step it runs on the low-priority stream beside the critical chain, whose
+// kernels then find no registers free until a 130 us tile retires (moment_dfb 93 -> 340 us, proposal_map_bwd_events2 485 -> 790 us
+// beside it).  24 KB of unused dynamic LDS per workgroup hold it to TWO per CU: measured 18.40 -> 18.25 ms/step on one box
+// (one per CU: 19.5).  SMIN_DW_EXTRA_LDS overrides (bytes; 0 = three per CU).
+int tn_extra_lds()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMIN_DW_EXTRA_LDS");
+        v = e ? atoi(e) : 24576;
+        if (v < 0) v = 0;
+        if (v > 96 * 1024) v = 96 * 1024;
+    }
+    return v;
+}
 
 // ---- launch timing (smin_prof_*): autograd runs backward on its own thread, hence the lock
 volatile int g_prof_on = 0;
