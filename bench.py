@@ -270,7 +270,8 @@ def main():
 
     # the same step with the contractions on the bf16 matrix cores (never the headline: `value` above is the exact-fp32 run)
     other = {}
-    if args.gemm == "f32" and not args.no_other_modes:
+    # (not under the in-node gradient exchange: it is limited to the exact-fp32 mode, distributed.wrap would have to be redone per mode)
+    if args.gemm == "f32" and not args.no_other_modes and not getattr(model, "grad_sync", False):
         def scores():
             with torch.no_grad():
                 return [o.float().clone() for o in net(batch["video_features"], batch["video_mask"], batch["query_features"], batch["query_mask"],
