@@ -20,6 +20,9 @@
 #include "gemm.h"
 #include "smin_hip.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace smin {
 
@@ -327,20 +330,26 @@ static int cl_num_cus()
     }
     return n;
 }
-// persistent exchange buffer per device (grown on demand; cleared ahead of every launch by the caller below)
-static unsigned long long* cl_exchange(size_t granules)
+// Exchange buffers, one per (device, direction), allocated ONCE at the size the largest geometry needs on this device (the cluster
+// count is capped by the CU count, so the bound does not depend on the batch): forward <= 256 CUs + 64 H granules, backward
+// <= 2048 CUs + 2048 P^2.  Never reallocated, so a captured graph's launches keep a valid address.  The step runs its recurrences
+// on one stream; two cluster recurrences in flight at once on one device (two streams, or two host threads) would share granules
+// and are not supported.
+static unsigned long long* cl_exchange(int which, size_t granules)
 {
-    static unsigned long long* buf[16] = {nullptr};
-    static size_t cap[16] = {0};
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::pair<unsigned long long*, size_t>> bufs;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (cap[dev] < granules) {
-        if (buf[dev]) (void)hipFree(buf[dev]);
-        buf[dev] = nullptr; cap[dev] = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&buf[dev]), granules * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        cap[dev] = granules;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& b = bufs[std::make_pair(dev, which)];
+    if (!b.first) {
+        const size_t ncu = (size_t)cl_num_cus();
+        const size_t cap = which == 0 ? 256 * ncu + 64 * 256 : 2048 * ncu + 2048 * 64;
+        if (hipMalloc(reinterpret_cast<void**>(&b.first), cap * sizeof(unsigned long long)) != hipSuccess) { b.first = nullptr; return nullptr; }
+        b.second = cap;
     }
-    return buf[dev];
+    return granules <= b.second ? b.first : nullptr;
 }
 
 bool bilstm_cluster_ok(int B, int Nq, int H)
@@ -369,7 +378,7 @@ int launch_bilstm_cluster_fwd(hipStream_t st, float* G, const float* W4, const i
         attr = true;
     }
     const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * H * CL_BS;
-    unsigned long long* xch = cl_exchange(gran > ((size_t)1 << 16) ? gran : ((size_t)1 << 16));
+    unsigned long long* xch = cl_exchange(0, gran);
     if (!xch) return -2;
     if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
     hipLaunchKernelGGL(bilstm_cluster_fwd_kernel, dim3(grid), dim3(256), lds, st, G, W4, len, B, Nq, H, P, nclus, Hout, Cs, xch);
@@ -389,7 +398,7 @@ int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G
         attr = true;
     }
     const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * P * P * CL_U * CL_BS;
-    unsigned long long* xch = cl_exchange(gran > ((size_t)1 << 16) ? gran : ((size_t)1 << 16));
+    unsigned long long* xch = cl_exchange(1, gran);
     if (!xch) return -2;
     if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
     hipLaunchKernelGGL(bilstm_cluster_bwd_kernel, dim3(grid), dim3(256), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, P, nclus, dG, xch);
