@@ -90,9 +90,13 @@ int smin_gate_fwd(void* stream, const float* fm, const float* fs, const int32_t*
 /* the same, and hsum_out = hsum_in + hbar [N][D] (running sum over layers, read by the next layers' gate term of chat) */
 int smin_gate_fwd_sum(void* stream, const float* fm, const float* fs, const int32_t* cells, int N, int D, float* hbar, const float* hsum_in,
                       float* hsum_out);
+/* boundary_A [B][L][L], boundary_dout [B][L][D] (both or neither; cells [N][4] then required): the boundary unit's consumer of hbar,
+ * f_bm[b,i] = sum_j A[b,i,j] hbar[b,i,j] (models.py:191-194), enters as A[b,i,j] * boundary_dout[b,i,:] formed on the fly -- pass the
+ * unit's saved attention A and the gradient of its output, and call smin_boundary_unit_bwd with dhbar == NULL. */
 int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhbar, const float* const* dres, int n_dres,
                   const float* fm, const float* fs, const int32_t* row_ptr,
-                  int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes);
+                  int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes,
+                  const int32_t* cells, const float* boundary_A, const float* boundary_dout);
 
 /* ---- ContentUnit.forward (models.py:242-276) incl. ContentAttention.forward (models.py:207-226).
  * Query-side per-sample operands are prepared by the host (O(B*Nq*dl) work):

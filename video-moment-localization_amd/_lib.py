@@ -34,7 +34,7 @@ SIGNATURES = {
     "smin_clip_event_table": [_vp] + [_i] * 3 + [_vp] * 3,
     "smin_gate_fwd": [_vp] * 4 + [_i] * 2 + [_vp],
     "smin_gate_fwd_sum": [_vp] * 4 + [_i] * 2 + [_vp] * 3,
-    "smin_gate_bwd": [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp] + [_i] * 4 + [_vp] * 2 + [_vp, _sz],
+    "smin_gate_bwd": [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp] + [_i] * 4 + [_vp] * 2 + [_vp, _sz] + [_vp] * 3,
     "smin_content_unit_fwd": [_vp] * 5 + [_i] * 7 + [_vp] * 9 + [_vp, _i] + [_vp] * 4,
     "smin_content_unit_bwd": [_vp] * 6 + [_i] * 7 + [_vp] * 9 + [_vp] * 10 + [_vp, _sz, _i],
     "smin_boundary_reduce_fwd": [_vp] * 5 + [_i] * 4 + [_vp],

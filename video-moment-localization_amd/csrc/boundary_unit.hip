@@ -43,7 +43,7 @@ void boundary_reduce_bwd_kernel(const float* __restrict__ dfbm, const float* __r
             const float4 dy = ldg4(dfbm + ((size_t)b * L + i) * D + d);
             const float4 x = ldg4(hbar + (size_t)n * D + d);
             dot = fmaf(dy.x, x.x, dot); dot = fmaf(dy.y, x.y, dot); dot = fmaf(dy.z, x.z, dot); dot = fmaf(dy.w, x.w, dot);
-            stg4(dhbar + (size_t)n * D + d, f4scale(dy, a));
+            if (dhbar) stg4(dhbar + (size_t)n * D + d, f4scale(dy, a));      // (NULL: the caller forms it itself, smin_gate_bwd)
         }
         dot = wave_sum(dot);
         if (lane == 0) darow[j] = dot;

@@ -40,7 +40,8 @@ __device__ __forceinline__ float4 grad_sum(const GradList& g, size_t off) {
 __global__ __launch_bounds__(128)
 void gate_bwd_kernel(GradList dh, GradList dres, const float* __restrict__ fm, const float* __restrict__ fs,
                      const int* __restrict__ row_ptr, int L, int D, int cells_per_chunk, int max_chunks,
-                     float* __restrict__ dfm, float* __restrict__ partial)
+                     float* __restrict__ dfm, float* __restrict__ partial,
+                     const int* __restrict__ cells, const float* __restrict__ bA, const float* __restrict__ dbm)
 {
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int s0 = row_ptr[b * L], s1 = row_ptr[(b + 1) * L];
@@ -56,8 +57,17 @@ void gate_bwd_kernel(GradList dh, GradList dres, const float* __restrict__ fm, c
             float4 ds[4], x[4], dr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t off = (size_t)min(n0 + u, n_end - 1) * D + d;
+                const int nn = min(n0 + u, n_end - 1);
+                const size_t off = (size_t)nn * D + d;
                 ds[u] = grad_sum(dh, off);                          // every consumer of hbar (summed here, not by autograd)
+                if (bA) {
+                    // ... the boundary unit's gated row reduction among them (models.py:191-194: f_bm[b,i] = sum_j A[b,i,j] hbar[b,i,j]):
+                    // its gradient A[b,i,j] * dbm[b,i,:] is a broadcast of a per-row vector, formed here from [B][L][L] + [B][L][D]
+                    // operands instead of being written by the boundary unit and read back (2 x 206 MB per layer at the bench shape)
+                    const int ci = cells[4 * (size_t)nn + 1], cj = cells[4 * (size_t)nn + 2];
+                    const float a = bA[((size_t)b * L + ci) * L + cj];
+                    ds[u] = f4fma(ldg4(dbm + ((size_t)b * L + ci) * D + d), a, ds[u]);
+                }
                 x[u] = ldg4(fm + off);
                 dr[u] = dres.n > 0 ? grad_sum(dres, off) : f4zero();   // gradients of the pass-through copies of f_m
             }
@@ -134,9 +144,10 @@ extern "C" int smin_gate_fwd_sum(void* stream, const float* fm, const float* fs,
 
 extern "C" int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhbar, const float* const* dres, int n_dres,
                              const float* fm, const float* fs, const int32_t* row_ptr,
-                             int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes)
+                             int N, int B, int L, int D, float* dfm, float* dfs, void* ws, size_t ws_bytes,
+                             const int32_t* cells, const float* boundary_A, const float* boundary_dout)
 {
-    (void)N;
+    SMIN_REQUIRE((boundary_A == nullptr) == (boundary_dout == nullptr) && (boundary_A == nullptr || cells != nullptr || N == 0));
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && n_dhbar >= 1 && n_dhbar <= 4 && n_dres >= 0 && n_dres <= 4);
     int cpc, mc; chunking_fine(L, &cpc, &mc);
@@ -145,7 +156,7 @@ extern "C" int smin_gate_bwd(void* stream, const float* const* dhbar, int n_dhba
     GradList gh, gr;
     for (int k = 0; k < 4; ++k) { gh.p[k] = dhbar[k < n_dhbar ? k : 0]; gr.p[k] = n_dres > 0 ? dres[k < n_dres ? k : 0] : nullptr; }
     gh.n = n_dhbar; gr.n = n_dres;
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, gh, gr, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(mc, B), dim3(128), 0, st, gh, gr, fm, fs, row_ptr, L, D, cpc, mc, dfm, partial, cells, boundary_A, boundary_dout);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_partial_reduce_kernel, dim3(cdiv(D / 4, 64), B), dim3(64, SPR_PH), 0, st, partial, row_ptr, L, D, cpc, mc, dfs);
     SMIN_LAUNCH_CHECK();

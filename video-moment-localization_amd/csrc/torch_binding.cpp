@@ -550,7 +550,7 @@ struct Gate : torch::autograd::Function<Gate> {
         Tensor dfm = at::empty_like(fm), dfs = at::empty_like(fs);
         auto ws = scratch((size_t)4 * B * 512 * D + 4096, fm.device());
         SMIN_CK(smin_gate_bwd(cur(), dh.data(), i32(dh.size()), dr.empty() ? nullptr : dr.data(), i32(dr.size()), fp(fm), fp(fs), ip(row_ptr), N, B, L, D,
-                              fpm(dfm), fpm(dfs), ws.p, ws.n));
+                              fpm(dfm), fpm(dfs), ws.p, ws.n, nullptr, nullptr, nullptr));
         return {dfm, dfs, undef(), undef(), undef(), undef(), undef(), undef()};
     }
 };
@@ -1121,25 +1121,27 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                              nullptr, nullptr, ws.p, ws.n, 1, fp(dcum_next), nullptr));          // (the pair product feeds the weight half only)
             }
             // boundary unit on the second stream
-            Tensor dfb_k, dhbar_b;
+            // (the boundary unit's gradient of hbar, A[b,i,j] * dbu[b,i,:], is formed by the gate backward itself from A and dbu: no [N][D]
+            //  tensor written here and read back there)
+            Tensor dfb_k, dbu;
             wait_stream(side, curs);
             {
                 StreamScope sc(side);
                 const float* two[2] = {fp(dfb_next), fp(dfb_mu)};
-                Tensor dbu = at::empty({B, L, D}, opt);
+                dbu = at::empty({B, L, D}, opt);
                 SMIN_CK(smin_sum_lists(cur(), two, 2, (size_t)dbu.numel(), fpm(dbu)));
-                dfb_k = at::empty({B, L, D}, opt); dhbar_b = at::empty({N, D}, opt);
+                dfb_k = at::empty({B, L, D}, opt);
                 Tensor dfw = at::empty_like(fw), dfs = at::empty_like(fs);
                 Tensor dWq = at::empty({D, D}, opt), dbq = at::empty({D}, opt), dWk = at::empty({D, D}, opt), dbk = at::empty({D}, opt);
                 const size_t nbytes = 4 * ((size_t)2 * B * L * L + (size_t)3 * B * L * D + (size_t)B * L * Nq + (size_t)B * Nq * D + (size_t)2 * 64 * ((size_t)D * D + D)) + 4096;
                 auto ws = scratch(nbytes, dev);
                 SMIN_CK(smin_boundary_unit_bwd(cur(), fp(dbu), fp(ls.fb), fp(fw), fp(fs), fp(ls.hbar), ip(cells), ip(row_ptr), n, B, Li, Nq, D, fp(trk(k, TR_BQ)), fp(trk(k, TR_BK)),
-                                               fp(qmf), fp(lmf), fp(ls.Qb), fp(ls.Kb), fp(ls.P), fp(ls.baq), fp(ls.bqv), fp(ls.A), fpm(dfb_k), fpm(dfw), fpm(dfs), fpm(dhbar_b),
+                                               fp(qmf), fp(lmf), fp(ls.Qb), fp(ls.Kb), fp(ls.P), fp(ls.baq), fp(ls.bqv), fp(ls.A), fpm(dfb_k), fpm(dfw), fpm(dfs), nullptr,
                                                fpm(dWq), fpm(dbq), fpm(dWk), fpm(dbk), ws.p, ws.n));
                 dlp(k, L_BQ_W) = dWq; dlp(k, L_BQ_B) = dbq; dlp(k, L_BK_W) = dWk; dlp(k, L_BK_B) = dbk;
                 sync.reduce({dWq, dbq, dWk, dbk}, side);
                 dfs_parts.push_back(dfs); dfw_parts.push_back(dfw);
-                keep.push_back(dfb_next); keep.push_back(dfb_mu); keep.push_back(dhbar_b);
+                keep.push_back(dfb_next); keep.push_back(dfb_mu); keep.push_back(dbu);
             }
             // clip-mean update cum = ccmean Wc^T + b + cumean + hbar: d ccmean, weight gradients; d cumean = d hbar = dcum
             Tensor dccmean = at::empty({N, dl}, opt);
@@ -1226,14 +1228,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
             {
                 std::vector<Tensor> later;
                 for (int64_t kk = k + 1; kk < nl; ++kk) later.push_back(dHs[kk]);
-                std::vector<const float*> dh{fp(dcum), fp(dhbar_b)}, dr{fp(dfm)};
+                std::vector<const float*> dh{fp(dcum)}, dr{fp(dfm)};
                 Tensor later_sum;
-                if (later.size() <= 2) for (auto& t : later) dh.push_back(fp(t));
+                if (later.size() <= 3) for (auto& t : later) dh.push_back(fp(t));
                 else { later_sum = sum_list(later); dh.push_back(fp(later_sum)); }
                 if (k == 0) dr.push_back(fp(dcum));
                 Tensor dfm_k = at::empty({N, D}, opt), dfs = at::empty_like(fs);
                 auto ws = scratch((size_t)4 * B * 512 * D + 4096, dev);
-                SMIN_CK(smin_gate_bwd(cur(), dh.data(), i32(dh.size()), dr.data(), i32(dr.size()), fp(ls.fm), fp(fs), ip(row_ptr), n, B, Li, D, fpm(dfm_k), fpm(dfs), ws.p, ws.n));
+                SMIN_CK(smin_gate_bwd(cur(), dh.data(), i32(dh.size()), dr.data(), i32(dr.size()), fp(ls.fm), fp(fs), ip(row_ptr), n, B, Li, D, fpm(dfm_k), fpm(dfs), ws.p, ws.n,
+                                      ip(cells), fp(ls.A), fp(dbu)));
                 dfs_parts.push_back(dfs);
                 dfm = dfm_k;
             }

@@ -371,7 +371,7 @@ class GateFn(Function):
         dfm, dfs = torch.empty_like(fm), torch.empty_like(fs)
         _, wp, wn = _ws(4 * layout.B * 512 * D + 4096, fm.device)
         call("smin_gate_bwd", stream(), _ptr_array(dh), len(dh), _ptr_array(dr) if dr else None, len(dr), ptr(fm), ptr(fs),
-             ptr(layout.row_ptr), N, layout.B, layout.L, D, ptr(dfm), ptr(dfs), wp, wn)
+             ptr(layout.row_ptr), N, layout.B, layout.L, D, ptr(dfm), ptr(dfs), wp, wn, None, None, None)
         return dfm, dfs, None, None, None
 
 
