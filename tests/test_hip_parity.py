@@ -823,7 +823,7 @@ def test_content_stream_equals_unit_as_written(dev, name):
 
 
 # ---------------------------------------------------------------- query encoder: fused BiLSTM layer kernels
-@pytest.mark.parametrize("B,Nq,H", [(5, 7, 16), (64, 20, 256), (3, 32, 64), (1, 4, 32)])
+@pytest.mark.parametrize("B,Nq,H", [(5, 7, 16), (64, 20, 256), (3, 32, 64), (1, 4, 32), (6, 9, 128), (37, 5, 256)])
 def test_query_encoder_matches_packed_lstm(dev, B, Nq, H):
     """QueryEncoder on the HIP BiLSTM kernels against the reference formulation (models.py:46-63): nn.LSTM over
     pack_padded_sequence / pad_packed_sequence in fp64 on the CPU -- outputs and every parameter gradient."""
@@ -1295,3 +1295,37 @@ def test_standalone_attention_classes_against_oracle(dev):
             for name, p in mod.named_parameters():
                 ref = sd["x." + name].grad
                 assert (p.grad.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5 * gmax, (cls.__name__, name)
+
+
+def test_captured_step_with_optimizer_matches_eager_training(dev):
+    """The captured step including the (capturable, fused) Adam update: after its three warm-up steps and one replay the
+    parameters equal those of four eager steps on the same batch, bit for bit; further replays keep matching."""
+    import models
+    from oracle import smin_oracle as O
+    from vml_amd import CapturedStep, loss_fn
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 32, 8, 4, 64, 32, 2, 24, 6, 32, 3
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    b = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=21).items()}
+    cfg = dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh)
+    m_e, m_c = build_model(cfg, sd, dev), build_model(cfg, sd, dev)
+    opt_e = torch.optim.Adam(m_e.parameters(), lr=1e-3, fused=True, capturable=True)
+    opt_c = torch.optim.Adam(m_c.parameters(), lr=1e-3, fused=True, capturable=True)
+
+    def eager_step():
+        opt_e.zero_grad(set_to_none=True)
+        out = m_e(*H.model_inputs(b))
+        loss = loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"])
+        loss.backward()
+        opt_e.step()
+        return loss.detach().clone()
+
+    step = CapturedStep(m_c, opt_c)
+    for it in range(3):
+        loss_c, _ = step(b)                                         # first call: three eager warm-up steps + capture + one replay
+        n_eager = 4 if it == 0 else 1
+        for _ in range(n_eager):
+            loss_e = eager_step()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_c.detach(), loss_e), it
+        for (k, pe), (_, pc) in zip(m_e.named_parameters(), m_c.named_parameters()):
+            assert torch.equal(pe, pc), (it, k)
