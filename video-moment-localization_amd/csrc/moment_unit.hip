@@ -41,8 +41,9 @@ void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ 
     // every row of dX1 is read twice, by the workgroup of its start snippet and by that of its end snippet: all workgroups of a
     // sample sit on ONE XCD (ids id and id + 8 share an XCD under round-robin placement: speed only), so that the second read is
     // an L2 hit while the sample's 4 MB of dX1 pass through (dealt over all eight L2s the launch fetched 2.0x the tensor)
-    const int id = blockIdx.x, slot = id >> 3;
-    const int l = slot % L, b = (slot / L) * 8 + (id & 7);
+    // (sample 8g + k on XCD class (k + g) mod 8: see proposal_map_bwd_events2_kernel)
+    const int id = blockIdx.x, slot = id >> 3, sg = slot / L;
+    const int l = slot % L, b = sg * 8 + (((id & 7) - sg) & 7);
     if (b >= B) return;
     const float* fbb = fb + (size_t)b * L * D;
     const int r0 = row_ptr[b * L + l], r1 = row_ptr[b * L + l + 1];

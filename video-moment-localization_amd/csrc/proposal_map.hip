@@ -263,8 +263,10 @@ void proposal_map_bwd_events2_kernel(Src src, const float* __restrict__ dfm,
     // only): a clip's gradient row is read at its start frame and again at its end frame, by two workgroups of the same sample
     // that are in flight together -- with (t, b) dealt over all eight L2s the second read went to the fabric (1.24 GB fetched for
     // 0.62 GB of rows).
-    const int id = blockIdx.x, slot = id >> 3;
-    const int t = slot % T, b = (slot / T) * 8 + (id & 7), tid = threadIdx.x;
+    // (sample 8g + k goes to XCD class (k + g) mod 8, not k: lengths often alternate with the sample index -- the synthetic batch's
+    //  even samples are full length, its odd ones ragged -- and a fixed class per residue left half of the XCDs with a quarter of the work)
+    const int id = blockIdx.x, slot = id >> 3, sg = slot / T;
+    const int t = slot % T, b = sg * 8 + (((id & 7) - sg) & 7), tid = threadIdx.x;
     if (b >= B) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int* cmap = cellmap + (size_t)b * L * L;
