@@ -286,8 +286,10 @@ void proposal_map_bwd_events2_kernel(Src src, const float* __restrict__ dfm,
         // resolve this round's table entries: (i, j) -> packed cell index, dropping absent and masked cells
         int wn = 0;
         Ev* mine = list + wave * EV_CAP;
-        const int lo = base + wave * EV_CAP, hi = min(ne, lo + EV_CAP);
-        for (int x0 = lo; x0 < hi; x0 += 64) {
+        // the two waves take alternate 64-entry chunks of the round (a frame has ~65 entries: with one contiguous half per wave the
+        // second wave idled through both dependent-load trips of the first)
+        const int hi = min(ne, base + 2 * EV_CAP);
+        for (int x0 = base + 64 * wave; x0 < hi; x0 += 128) {
             const int x = x0 + lane;
             Ev e = Ev{0, 0.f};
             int n = -1;
