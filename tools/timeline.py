@@ -56,3 +56,13 @@ for k, (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
 print("kernel time per step (us):")
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 45]:
     print(f"  {v/n/1e3:8.1f}  {k}")
+# optional: text Gantt of the last steady step -- one line per kernel: start offset (us), duration (us), queue, kernels in flight
+# at its start, name.      python tools/timeline.py <csv> 45 --gantt
+if "--gantt" in sys.argv:
+    a, b = steps[-1]
+    w = [e for e in ev if e[1] > a and e[0] < b]
+    print(f"gantt of the last steady step ({(b - a) / 1e6:.3f} ms):")
+    for s, e, k, q in w:
+        inflight = sum(1 for s2, e2, *_ in w if s2 <= s < e2)
+        short = k.replace("smin::", "").replace("void ", "")
+        print(f"  {(s - a) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  q{q} x{inflight}  {short[:110]}")

@@ -21,6 +21,7 @@
 #include <ATen/core/stack.h>
 
 #include <cmath>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -89,13 +90,18 @@ void record_stream(const Tensor& t, HStream s)
 {
     if (t.defined() && t.has_storage()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), s);
 }
-HStream side_stream(c10::DeviceIndex dev)
+HStream side_stream(c10::DeviceIndex dev, int which = 0)
 {
     static std::mutex mu;
-    static std::map<int, HStream> streams;
+    static std::map<std::pair<int, int>, HStream> streams;
     std::lock_guard<std::mutex> lk(mu);
-    auto it = streams.find(dev);
-    if (it == streams.end()) it = streams.emplace((int)dev, c10::hip::getStreamFromPool(false, dev)).first;
+    auto it = streams.find({(int)dev, which});
+    if (it == streams.end()) {
+        HStream st = c10::hip::getStreamFromPool(false, dev);
+        for (auto& kv : streams)                                  // the pool hands its streams out round robin: never the same one twice
+            while (kv.first.first == (int)dev && kv.second == st) st = c10::hip::getStreamFromPool(false, dev);
+        it = streams.emplace(std::make_pair((int)dev, which), st).first;
+    }
     return it->second;
 }
 
@@ -136,13 +142,14 @@ struct Layout {                           // packed valid-cell layout (SURVEY 8a
 };
 
 // the geometry's clip-boundary table, built once per (device, T, L, C)
-std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, int C)
+std::pair<Tensor, Tensor> clip_event_table(const at::Device& dev, int T, int L, int C, bool* built_now = nullptr)
 {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int>, std::pair<Tensor, Tensor>> tabs;
     std::lock_guard<std::mutex> lk(mu);
     auto key = std::make_tuple((int)dev.index(), T, L, C);
     auto it = tabs.find(key);
+    if (built_now) *built_now = it == tabs.end();                 // built on the CURRENT stream: a consumer on another stream has to wait for it
     if (it != tabs.end()) return it->second;
     auto io = at::TensorOptions().dtype(at::kInt).device(dev);
     Tensor counts = at::empty({T}, io);
@@ -1092,29 +1099,40 @@ struct SminCore : torch::autograd::Function<SminCore> {
         Tensor dwhat = at::empty_like(st.what), dshat = at::empty_like(st.shat), dMq = at::empty_like(st.Mq), duq = at::empty_like(st.uq);
         if (N == 0) { dwhat.zero_(); dshat.zero_(); dMq.zero_(); duq.zero_(); }
         Tensor dcum_next;                                                          // gradient of cum_k from layer k+1's clip-mean chain
+        auto mark_on = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
+        hipEvent_t attn0_done = nullptr;
+        static const bool defer_dw0 = std::getenv("SMIN_DEFER_DW0") && std::atoi(std::getenv("SMIN_DEFER_DW0")) != 0;
+        Tensor deferred_dfm;
+        std::function<void(const Tensor&)> deferred_weights;
         for (int64_t k = nl - 1; k >= 0; --k) {
             LayerState& ls = st.layer[k];
             // moment unit: dmu -> d cum (its chain gradient folded in), d bu, weight gradients; the residual gradient is dmu itself
             Tensor dcum = at::empty({N, D}, opt), dfb_mu = at::empty({B, L, D}, opt);
             keep.push_back(dfm); keep.push_back(dcum);
             // (measured: the weight half queued ahead of the input half 21.39 -> 21.15 ms/step, behind it 21.7 -> 21.6)
-            wait_stream(wstr, curs);
-            {
+            // Layer 0's (the last one of the loop) is held back until the proposal map's gradient is queued: started here it ran beside
+            // the HBM-bound closing kernels (gate backward, clip events) and stretched them 2-3x in front of the LSTM layers, which
+            // wait for all of them; started there it runs beside the LSTM recurrences (a few dozen workgroups) instead.
+            auto moment_weights = [&, k](const Tensor& dfm_in) {
+                LayerState& lsk = st.layer[k];
+                wait_stream(wstr, curs);
                 StreamScope sc(wstr);
-                Tensor dWcat = prep_kernel ? dWcat_all[k] : at::empty_like(ls.Wcat), dbcat = prep_kernel ? dbcat_all[k] : at::empty({D}, opt);
+                Tensor dWcat = prep_kernel ? dWcat_all[k] : at::empty_like(lsk.Wcat), dbcat = prep_kernel ? dbcat_all[k] : at::empty({D}, opt);
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
-                if (ls.x1.scalar_type() == at::kBFloat16)
-                    SMIN_CK(smin_moment_unit_bwd_x1h(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
-                                                     fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, reinterpret_cast<const uint16_t*>(ls.x1.const_data_ptr())));
+                if (lsk.x1.scalar_type() == at::kBFloat16)
+                    SMIN_CK(smin_moment_unit_bwd_x1h(cur(), fp(dfm_in), fp(lsk.cum), fp(lsk.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
+                                                     fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, reinterpret_cast<const uint16_t*>(lsk.x1.const_data_ptr())));
                 else
-                    SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
-                                                 fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(ls.x1)));
+                    SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm_in), fp(lsk.cum), fp(lsk.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
+                                                 fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(lsk.x1)));
                 if (!prep_kernel) {
                     dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
                     dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
                 }
                 sync.reduce({dWcat, dbcat}, wstr);                                   // inputs of the parameter-product kernel
-            }
+            };
+            if (k == 0 && defer_dw0 && wstr != curs) { deferred_dfm = dfm; deferred_weights = moment_weights; }
+            else moment_weights(dfm);
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), fpm(dcum), fpm(dfb_mu),
@@ -1157,6 +1175,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 SMIN_CK(smin_content_attn_bwd(cur(), fp(dcc[k]), fp(dccmean), fp(ls.chat), ip(cells), ip(row_ptr), n, B, Li, Ci, dl, Nq, fp(st.Mq[k]), fp(st.uq[k]), fp(st.what[k]),
                                               fp(st.shat[k]), fp(qmf), fpm(dchat[k]), fpm(dMq[k]), fpm(duq[k]), fpm(dwhat[k]), fpm(dshat[k]), ws.p, ws.n));
             }
+            if (k == 0) attn0_done = mark_on(curs);                                // every dchat / word-side gradient is final from here on
             // chat_k's contraction over the earlier layers' attention outputs, and its per-cell gate term: input gradients
             Tensor dhp;
             for (int64_t part = 0, lo = 0; lo < k; ++part, lo += 4) {
@@ -1243,15 +1262,24 @@ struct SminCore : torch::autograd::Function<SminCore> {
             dcum_next = dcum; dfb_next = dfb_k;
         }
 
-        // ---- the tail.  Second stream: word-side operands (0.9 ms of small-grid kernels at ActivityNet size), then the parameter
-        // products; main stream: clip-window / proposal-map gradients, video encoder, the two LSTM layers.
+        // ---- the tail.  Three chains leave the last attention backward (layer 0's) and meet again in front of the LSTM layers:
+        //   words  (own stream): the word-side operands' backward, 0.75 ms of small-grid kernels at ActivityNet size -> d f_w
+        //   tail   (the boundary stream): the clip-window gradients of every layer's chat -> dg; later the parameter products
+        //   main   : layer 0's gate backward (already queued above), the proposal map's gradient -> df, video encoder, LSTM layers
+        // (before: the first two waited for the gate backward and the clip-window pass sat between it and the proposal map on the
+        //  main stream -- 0.5 ms longer, tools/gantt.sh)
+        static const bool tail_split = !(std::getenv("SMIN_TAIL_SPLIT") && std::atoi(std::getenv("SMIN_TAIL_SPLIT")) == 0);   // 0: the round-2 placement (A/B)
         HStream tail = (flags & F_OVERLAP_PREP) ? side_stream(dev.index()) : curs;
-        auto mark = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
+        HStream wordst = !(flags & F_OVERLAP_PREP) ? curs : tail_split ? side_stream(dev.index(), 1) : tail;
+        HStream cw = tail_split ? tail : curs;                                      // stream of the clip-window gradients
+        auto mark = mark_on;
         auto await = [](HStream waiter, hipEvent_t e) { TORCH_CHECK(hipStreamWaitEvent(waiter.stream(), e, 0) == hipSuccess, "hipStreamWaitEvent failed"); };
+        if (!attn0_done) attn0_done = mark(curs);
         hipEvent_t words_done;
-        wait_stream(tail, curs);
+        if (!tail_split) wait_stream(wordst, curs);
+        else if (wordst != curs) await(wordst, attn0_done);
         {
-            StreamScope sc(tail);
+            StreamScope sc(wordst);
             std::vector<const float*> gp[4], pp;
             std::vector<float*> dp;
             for (int64_t k = 0; k < nl; ++k) {
@@ -1267,32 +1295,43 @@ struct SminCore : torch::autograd::Function<SminCore> {
             SMIN_CK(smin_word_prep_bwd(cur(), gp[0].data(), gp[1].data(), gp[2].data(), gp[3].data(), fp(fw), fp(fs), fp(qmf), fp(st.what), fp(st.kb), pp.data(), i32(nl), B, Nq, D,
                                        dl, fpm(dfw), fpm(dfs), dp.data(), ws.p, ws.n));
             dfw_parts.push_back(dfw); dfs_parts.push_back(dfs);
-            words_done = mark(tail);
+            words_done = mark(wordst);
             if (sync.on) {
                 std::vector<Tensor> ws_grads = loc_bufs;
                 for (int64_t k = 0; k < nl; ++k)
                     for (int which : {L_WH_W, L_WH_B, L_SH_W, L_SH_B, L_AK_W, L_AK_B, L_AQ_W, L_AQ_B}) ws_grads.push_back(dlp(k, which));
-                sync.reduce(ws_grads, tail);
+                sync.reduce(ws_grads, wordst);
             }
         }
 
-        // ---- clip-window terms of chat, the proposal map, f
+        // ---- clip-window terms of chat (tail stream), the proposal map (main stream), f
         Tensor df;
         hipEvent_t weights_done;
-        auto tab = clip_event_table(dev, Ti, Li, Ci);
+        bool tab_built = false;
+        auto tab = clip_event_table(dev, Ti, Li, Ci, &tab_built);
+        if (tab_built) wait_stream(cw, curs);                                    // first backward of this geometry only
         {
             std::vector<const float*> ptrs;
             for (int64_t k = 0; k < nl; ++k) ptrs.push_back(fp(dchat[k]));
             Tensor dg = at::empty({(int64_t)B * T, nl * dl}, opt);
-            auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
-            SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
-                                               tab.second.data_ptr()));
-            if (!prep_kernel) dconsts[0] = at::empty({dl}, opt);
             keep.push_back(dg);
-            const float* xs[1] = {fp(f)};
-            wait_stream(wstr, curs);
+            if (cw != curs) await(cw, attn0_done);
+            hipEvent_t dg_done;
             {
-                StreamScope sc(wstr);
+                StreamScope sc(cw);
+                auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
+                SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
+                                                   tab.second.data_ptr()));
+                dg_done = mark(cw);
+            }
+            if (!tail_split) wait_stream(wstr, curs);
+            {
+                StreamScope sc(tail_split ? tail : wstr);
+                // the weight gradient of the clip-window contraction stays on this stream (its only consumer is the parameter-product kernel
+                // queued here below).  NOT on the weight stream: that stream would wait for this one and this one for it, and two forked
+                // streams that wait for each other's events send hipStreamEndCapture into an endless recursion (captured step).
+                if (!prep_kernel) dconsts[0] = at::empty({dl}, opt);
+                const float* xs[1] = {fp(f)};
                 dWch_all = at::empty_like(st.Wch_all);
                 auto wsw = scratch(smin_linear_rows_bwd_workspace_bytes(i32(B * T), i32(nl * dl), D), dev);
                 SMIN_CK(smin_linear_rows_bwd(cur(), fp(dg), xs, 1, nullptr, i32(B * T), i32(nl * dl), D, nullptr, fpm(dWch_all), nullptr, wsw.p, wsw.n));
@@ -1301,14 +1340,16 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 auto wsc = scratch(smin_col_sum_workspace_bytes(i32(N * C), dl), dev);
                 SMIN_CK(smin_col_sum(cur(), fp(dchat[0]), i32(N * C), dl, fpm(dconsts[0]), wsc.p, wsc.n));
             }
-            weights_done = mark(wstr);
             // df = gradient through the proposal map (f_m, f_b) + gradient through the clip-window terms, the second accumulated by its
             // contraction's epilogue
             df = at::empty({B, T, D}, opt);
             auto ws3 = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
             SMIN_CK(smin_proposal_map_bwd(cur(), nullptr, fp(dfm), fp(dfb_next), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, D, fpm(df), ws3.p, ws3.n, ip(tab.first),
                                           tab.second.data_ptr()));
+            if (deferred_weights) { deferred_weights(deferred_dfm); deferred_weights = nullptr; }
+            weights_done = mark(wstr);
             float* dxs[1] = {fpm(df)};
+            if (cw != curs) await(curs, dg_done);
             SMIN_CK(smin_linear_rows_dx_acc(cur(), fp(dg), 1, fp(Wch_allT), i32(B * T), i32(nl * dl), D, dxs));
         }
 
@@ -1363,6 +1404,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
         // ---- backbone on the main stream: video encoder, sentence / word features, the two LSTM layers (models.py:38-83)
         std::vector<Tensor> dbb(P_LAYER0), lstm_bufs;
+        // the backbone's weight halves: on the word stream (idle by now) when there is one -- the weight stream still holds layer 0's
+        // moment-unit contraction, and these short kernels close the step
+        HStream bstr = (tail_split && wordst != curs && wstr != curs) ? wordst : wstr;
         {
             const int Din = i32(st.vx.size(2));
             const int64_t pe_rows = all[P_PE].size(0);
@@ -1380,15 +1424,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
             SMIN_CK(smin_video_encoder_bwd(cur(), fp(df), fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, nullptr, nullptr, nullptr, fpm(dfs_video), wsv.data_ptr(),
                                            (size_t)wsv.numel()));
             dfs_parts.push_back(dfs_video);
-            if (tail != curs) await(curs, words_done);
+            if (wordst != curs) await(curs, words_done);
             Tensor dfs_total = sum_list(dfs_parts), dfw_total = sum_list(dfw_parts);
             // f_s = [f_w[b, len_b - 1, :H] | f_w[b, 0, H:]] (models.py:60-62)
             SMIN_CK(smin_sentence_feature_bwd(cur(), fp(dfs_total), ip(st.len32), B, Nq, i32(H), fpm(dfw_total)));
             Tensor dH = Nq_in < Nq ? dfw_total.slice(1, 0, Nq_in).contiguous() : dfw_total;
             keep.push_back(dfs_total); keep.push_back(dfw_total); keep.push_back(dH); keep.push_back(df);
-            wait_stream(wstr, curs);
+            wait_stream(bstr, curs);
             {
-                StreamScope sc(wstr);
+                StreamScope sc(bstr);
                 SMIN_CK(smin_video_encoder_bwd(cur(), nullptr, fp(st.fv), fp(fs), fp(st.vmaskf), fp(st.vx), B, Ti, Din, D, fpm(dbb[P_VE_W]), fpm(dbb[P_VE_B]), fpm(dbb[P_PE]),
                                                nullptr, wsv.data_ptr(), (size_t)wsv.numel()));
             }
@@ -1401,9 +1445,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 Tensor wsl = own(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh));
                 SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
                                               fpm(dX), nullptr, nullptr, nullptr, wsl.data_ptr(), (size_t)wsl.numel()));
-                wait_stream(wstr, curs);
+                wait_stream(bstr, curs);
                 {
-                    StreamScope sc(wstr);
+                    StreamScope sc(bstr);
                     SMIN_CK(smin_bilstm_layer_bwd(cur(), nullptr, fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
                                                   nullptr, fpm(dWih), fpm(dbias), fpm(dWhh), wsl.data_ptr(), (size_t)wsl.numel()));
                 }
@@ -1417,6 +1461,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
         }
         wait_stream(curs, tail);
         wait_stream(curs, wstr);
+        wait_stream(curs, wordst);
         if (sync.on) {
             std::vector<Tensor> late{dbb[P_VE_W], dbb[P_VE_B], dbb[P_PE]};
             for (auto& t : lstm_bufs) late.push_back(t);
