@@ -335,6 +335,11 @@ size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H);
 int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, const float* Hout, const float* G, const float* Cs,
                           const float* Wih_catT, const float* Whh, const int32_t* len, int B, int Nq, int In, int H,
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
+/* The weights half in up to three independent pieces, each with its own part of ws (which: bit 0 = dWih_cat + dbias_cat, bit 1 =
+ * dWhh[0], bit 2 = dWhh[1]; 7 = what smin_bilstm_layer_bwd's weights half does): pieces issued on different streams run side by
+ * side behind the inputs half (they are the last kernels of a train step, models.py:46-62 backward). */
+int smin_bilstm_layer_bwd_weights(void* stream, int which, const float* X, const float* Hout, int B, int Nq, int In, int H,
+                                  float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
 
 /* The recurrences above run, for H a multiple of 32, as clusters of workgroups that keep W_hh in LDS and exchange h / dh through
  * tagged granules in global memory (csrc/bilstm_cluster.hip); every poll there is bounded.  Returns 1 once a poll has expired since

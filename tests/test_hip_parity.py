@@ -1020,15 +1020,19 @@ def test_step_helpers_through_the_c_abi(dev):
         ws = torch.zeros(nbl2 + 64, dtype=torch.uint8, device=dev)
         dX, dWih, dbi, dWhh = torch.full((B, Nq, In), 7.0, device=dev), torch.full((8 * Hh, In), 7.0, device=dev), torch.full((8 * Hh,), 7.0, device=dev), torch.full((2, 4 * Hh, Hh), 7.0, device=dev)
         args = (ptr(xq), ptr(Ho), ptr(G), ptr(Cs), ptr(WihT), ptr(Whh), ptr(length), B, Nq, In, Hh)
-        if split:
+        if split == "pieces":                                    # inputs half, then the weights half piece by piece in another order
+            call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), None, None, None, ptr(ws), ws.numel())
+            for which in (4, 1, 2):
+                call("smin_bilstm_layer_bwd_weights", stream(), which, ptr(xq), ptr(Ho), B, Nq, In, Hh, ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
+        elif split:
             call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), None, None, None, ptr(ws), ws.numel())
             assert float(dWih.min()) == 7.0 and float(dWhh.min()) == 7.0
             call("smin_bilstm_layer_bwd", stream(), None, *args, None, ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
         else:
             call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
         return dX, dWih, dbi, dWhh
-    for a, b in zip(lstm_bwd(False), lstm_bwd(True)):
-        assert torch.equal(a, b)
+    for a, b, c in zip(lstm_bwd(False), lstm_bwd(True), lstm_bwd("pieces")):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("cut", [False, True])

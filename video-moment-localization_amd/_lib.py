@@ -85,6 +85,7 @@ SIGNATURES = {
     "smin_sentence_feature_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_bilstm_layer_bwd_workspace_bytes": [_i] * 4,
     "smin_bilstm_layer_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
+    "smin_bilstm_layer_bwd_weights": [_vp, _i, _vp, _vp] + [_i] * 4 + [_vp] * 3 + [_vp, _sz],
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
             "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz,

@@ -218,11 +218,12 @@ void bilstm_bwd_kernel(const float* __restrict__ dHout, const float* __restrict_
 }
 
 // Hprev[d][b][p][:] = h of direction d one step before position p: Hout[b][p-1][0:H] (d = 0), Hout[b][p+1][H:2H] (d = 1)
-__global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int Nq, int H, float* __restrict__ Hprev)
+// (directions d0 .. d0 + nd - 1; Hprev is indexed from direction 0 either way)
+__global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int Nq, int H, float* __restrict__ Hprev, int d0, int nd)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t tot = (size_t)2 * B * Nq * H;
-    if (idx >= tot) return;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nd * B * Nq * H) return;
+    idx += (size_t)d0 * B * Nq * H;
     const int u = (int)(idx % H);
     const size_t r = idx / H;
     const int p = (int)(r % Nq);
@@ -335,7 +336,7 @@ extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, i
 {
     const int R = B * Nq;
     const size_t sp1 = (size_t)tn_splits(R, 8 * H, In), sp2 = (size_t)tn_splits(R, 4 * H, H);
-    return sizeof(float) * ((size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + sp2 * (size_t)4 * H * H + 256);
+    return sizeof(float) * ((size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + 2 * sp2 * (size_t)4 * H * H + 256);
 }
 
 // dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H].
@@ -351,8 +352,6 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
     const int R = B * Nq, H4 = 4 * H, H8 = 8 * H;
     float* w = reinterpret_cast<float*>(ws);
     float* dG = w;
-    float* Hprev = dG + (size_t)R * H8;
-    float* slab = Hprev + (size_t)2 * R * H;
     const int Hp = cdiv(H, 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)H4 * LSTM_BS + (size_t)16 * LSTM_BS * Hp);
     SMIN_REQUIRE(H4 % 16 == 0);
@@ -374,19 +373,42 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
         }
     }
     if (!dWih_cat) return 0;
-    const int sp1 = tn_splits(R, H8, In);
+    return smin_bilstm_layer_bwd_weights(stream, 7, X, Hout, B, Nq, In, H, dWih_cat, dbias_cat, dWhh, ws, ws_bytes);
+}
+
+// The weights half in up to three independent pieces (which: bit 0 = dWih_cat + dbias_cat, bit 1 = dWhh[0], bit 2 = dWhh[1]), each
+// with its own part of ws: issued on three streams they run side by side -- they are the last kernels of a train step, one after
+// the other they were ~0.2 ms of seven short launches behind the last recurrence.
+extern "C" int smin_bilstm_layer_bwd_weights(void* stream, int which, const float* X, const float* Hout, int B, int Nq, int In, int H,
+                                             float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SMIN_REQUIRE(In % 4 == 0 && H % 4 == 0 && H >= 4 && H <= 256 && B >= 1 && Nq >= 1 && which >= 1 && which <= 7);
+    SMIN_REQUIRE(ws_bytes >= smin_bilstm_layer_bwd_workspace_bytes(B, Nq, In, H));
+    const int R = B * Nq, H4 = 4 * H, H8 = 8 * H;
+    float* w = reinterpret_cast<float*>(ws);
+    float* dG = w;
+    float* Hprev = dG + (size_t)R * H8;
+    float* slab = Hprev + (size_t)2 * R * H;
+    const int sp1 = tn_splits(R, H8, In), sp2 = tn_splits(R, H4, H);
     float* bslab = slab + (size_t)sp1 * H8 * In;
-    rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
-    rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1); if (rc) return rc;
-    const size_t tot = (size_t)2 * R * H;
-    hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev);
-    SMIN_LAUNCH_CHECK();
-    const int sp2 = tn_splits(R, H4, H);
     float* slab2 = bslab + (size_t)sp1 * H8;
+    int rc;
+    if (which & 1) {
+        SMIN_REQUIRE(dWih_cat != nullptr && dbias_cat != nullptr);
+        rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
+        rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1); if (rc) return rc;
+    }
     for (int d = 0; d < 2; ++d) {
-        rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, PlainMat{Hprev + (size_t)d * R * H, H}, slab2, (float*)nullptr, R, H4, H, sp2);
+        if (!(which & (2 << d))) continue;
+        SMIN_REQUIRE(dWhh != nullptr);
+        const size_t tot = (size_t)R * H;
+        hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, d, 1);
+        SMIN_LAUNCH_CHECK();
+        float* sl = slab2 + (size_t)d * sp2 * H4 * H;
+        rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, PlainMat{Hprev + (size_t)d * R * H, H}, sl, (float*)nullptr, R, H4, H, sp2);
         if (rc) return rc;
-        rc = launch_reduce_slabs(st, slab2, dWhh + (size_t)d * H4 * H, H4 * H, sp2); if (rc) return rc;
+        rc = launch_reduce_slabs(st, sl, dWhh + (size_t)d * H4 * H, H4 * H, sp2); if (rc) return rc;
     }
     return 0;
 }

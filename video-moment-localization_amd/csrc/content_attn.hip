@@ -27,7 +27,6 @@
 namespace smin {
 
 constexpr int LDW = 36;                                       // row stride of the transposed [d][slot] LDS image
-constexpr int LDP = 36;                                       // row stride of the dS / P round tiles [row][slot]
 
 template <int CTRL>
 __device__ __forceinline__ float qperm(float v) {             // quad permute (DPP): neighbour lane j ^ o

@@ -69,6 +69,22 @@ void proposal_map_fwd_kernel(const double* __restrict__ Pf, const int* __restric
     const float inv32 = 1.0f / (float)cs;                         // the reference stores 1/clip_size in fp32
     const double inv = (double)inv32;
     const double* P = Pf + (size_t)cl.b * (T + 1) * D;
+    if (!fc) {
+        // f_m alone: the cell's clips are consecutive windows of cs frames starting at frame i*r, so the sum of their means telescopes to
+        // ONE difference of the prefix -- two row reads per cell instead of C + 1 (the kernel is bound by the L2 reads of the fp64 rows).
+        // One rounding instead of C + 1: within an ulp or two of the clip-by-clip sum the reference forms (models.py:117-119).
+        const double scale = inv / (double)C;
+        for (int d = threadIdx.x * 4; d < D; d += 512) {
+            float4 v = f4zero();
+            if (nclip > 0) {
+                const double* pb = P + (size_t)(cl.i * r) * D + d;
+                const double* pe = pb + (size_t)(nclip * cs) * D;
+                v = make_float4((float)((pe[0] - pb[0]) * scale), (float)((pe[1] - pb[1]) * scale), (float)((pe[2] - pb[2]) * scale), (float)((pe[3] - pb[3]) * scale));
+            }
+            stg4(fm + (size_t)n * D + d, v);
+        }
+        return;
+    }
     for (int d = threadIdx.x * 4; d < D; d += 512) {
         float4 sum = f4zero();
         // consecutive clips share a boundary row of the prefix: nclip + 1 row reads instead of 2 * nclip
@@ -83,7 +99,7 @@ void proposal_map_fwd_kernel(const double* __restrict__ Pf, const int* __restric
                 v.z = (float)((hi.z - lo.z) * inv); v.w = (float)((hi.w - lo.w) * inv);
                 lo = hi;
             }
-            if (fc) stg4(fc + ((size_t)n * C + c) * D + d, v);
+            stg4(fc + ((size_t)n * C + c) * D + d, v);
             sum = f4add(sum, v);
         }
         if (fm) stg4(fm + (size_t)n * D + d, make_float4(sum.x / C, sum.y / C, sum.z / C, sum.w / C));

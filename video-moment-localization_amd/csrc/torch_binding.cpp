@@ -1110,9 +1110,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
             Tensor dcum = at::empty({N, D}, opt), dfb_mu = at::empty({B, L, D}, opt);
             keep.push_back(dfm); keep.push_back(dcum);
             // (measured: the weight half queued ahead of the input half 21.39 -> 21.15 ms/step, behind it 21.7 -> 21.6)
-            // Layer 0's (the last one of the loop) is held back until the proposal map's gradient is queued: started here it ran beside
-            // the HBM-bound closing kernels (gate backward, clip events) and stretched them 2-3x in front of the LSTM layers, which
-            // wait for all of them; started there it runs beside the LSTM recurrences (a few dozen workgroups) instead.
+            // SMIN_DEFER_DW0=1 (experiment, off): layer 0's (the last one of the loop) held back until the proposal map's gradient is
+            // queued, so that it does not stretch the HBM-bound closing kernels.  Measured WORSE (17.8 vs 17.6 ms): it then runs beside
+            // the cluster LSTM, whose workgroups need a CU's whole LDS and wait for CUs this contraction has drained (177 -> 1225 us).
             auto moment_weights = [&, k](const Tensor& dfm_in) {
                 LayerState& lsk = st.layer[k];
                 wait_stream(wstr, curs);
@@ -1313,12 +1313,15 @@ struct SminCore : torch::autograd::Function<SminCore> {
         {
             std::vector<const float*> ptrs;
             for (int64_t k = 0; k < nl; ++k) ptrs.push_back(fp(dchat[k]));
-            Tensor dg = at::empty({(int64_t)B * T, nl * dl}, opt);
-            keep.push_back(dg);
             if (cw != curs) await(cw, attn0_done);
             hipEvent_t dg_done;
+            Tensor dg;
             {
                 StreamScope sc(cw);
+                // allocated under THIS stream: a block from the main stream's pool may still be read by main-stream kernels queued behind
+                // attn0_done (the allocator only orders reuse within the stream a block was allocated on)
+                dg = at::empty({(int64_t)B * T, nl * dl}, opt);
+                keep.push_back(dg);
                 auto ws = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
                 SMIN_CK(smin_clip_window_means_bwd(cur(), ptrs.data(), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, dl, i32(nl), fpm(dg), ws.p, ws.n, ip(tab.first),
                                                    tab.second.data_ptr()));
@@ -1445,11 +1448,14 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 Tensor wsl = own(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh));
                 SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
                                               fpm(dX), nullptr, nullptr, nullptr, wsl.data_ptr(), (size_t)wsl.numel()));
-                wait_stream(bstr, curs);
-                {
-                    StreamScope sc(bstr);
-                    SMIN_CK(smin_bilstm_layer_bwd(cur(), nullptr, fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
-                                                  nullptr, fpm(dWih), fpm(dbias), fpm(dWhh), wsl.data_ptr(), (size_t)wsl.numel()));
+                // the weight gradients: three independent pieces; the last layer's (nothing else is left to run by then) on three streams
+                HStream piece[3] = {bstr, bstr, bstr};
+                if (layer == 0 && bstr == wordst && tail != curs) { piece[1] = tail; piece[2] = wstr; }
+                for (int pc = 0; pc < 3; ++pc) {
+                    if (pc == 0 || piece[pc] != piece[pc - 1]) wait_stream(piece[pc], curs);
+                    StreamScope sc(piece[pc]);
+                    SMIN_CK(smin_bilstm_layer_bwd_weights(cur(), 1 << pc, fp(ls.x), fp(ls.Hout), B, i32(Nq_in), In, Hh, fpm(dWih), fpm(dbias), fpm(dWhh), wsl.data_ptr(),
+                                                          (size_t)wsl.numel()));
                 }
                 if (dX.defined()) keep.push_back(dX);
                 const int64_t H4 = 4 * H;
