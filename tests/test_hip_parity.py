@@ -823,6 +823,45 @@ def test_content_stream_equals_unit_as_written(dev, name):
 
 
 # ---------------------------------------------------------------- query encoder: fused BiLSTM layer kernels
+def test_cluster_recurrences_from_two_streams_take_turns(dev):
+    """Two query encoders stepped on two streams at once: the cluster recurrence (W_hh resident in LDS, one workgroup per CU,
+    granule exchange through one buffer per device) must not run twice at a time -- the library orders the launches behind each
+    other.  Results equal the one-stream results bit for bit and no bounded poll expires."""
+    import models
+    B, Nq, H = 64, 20, 256
+    g = torch.Generator().manual_seed(77)
+    qes = []
+    for _ in range(2):
+        qe = models.QueryEncoder(Nq, H)
+        for p in qe.parameters():
+            p.data = (torch.rand(p.shape, generator=g) - 0.5) * 0.6
+        qes.append(qe.to(dev))
+    xs = [torch.randn(B, Nq, 300, generator=g).to(dev) for _ in range(2)]
+    mask = torch.ones(B, Nq, 1, dtype=torch.uint8, device=dev)
+
+    def step(qe, x):
+        qe.zero_grad(set_to_none=True)
+        fs, fw = qe(x, mask)
+        (fw.sum() + fs.sum()).backward()
+        return [fs.detach().clone(), fw.detach().clone()] + [p.grad.clone() for p in qe.parameters()]
+
+    ref = [step(qe, x) for qe, x in zip(qes, xs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        got = []
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        for qe, x, s in zip(qes, xs, streams):
+            with torch.cuda.stream(s):
+                got.append(step(qe, x))
+        torch.cuda.synchronize()
+        for r, o in zip(ref, got):
+            for a, b in zip(r, o):
+                assert torch.equal(a, b)
+    assert models.vml_amd._lib.load().smin_lstm_cluster_error() == 0, "a bounded poll of the cluster recurrence expired"
+
+
 @pytest.mark.parametrize("B,Nq,H", [(5, 7, 16), (64, 20, 256), (3, 32, 64), (1, 4, 32), (6, 9, 128), (37, 5, 256)])
 def test_query_encoder_matches_packed_lstm(dev, B, Nq, H):
     """QueryEncoder on the HIP BiLSTM kernels against the reference formulation (models.py:46-63): nn.LSTM over

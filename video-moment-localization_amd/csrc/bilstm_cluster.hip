@@ -333,8 +333,10 @@ static int cl_num_cus()
 // Exchange buffers, one per (device, direction), allocated ONCE at the size the largest geometry needs on this device (the cluster
 // count is capped by the CU count, so the bound does not depend on the batch): forward <= 256 CUs + 64 H granules, backward
 // <= 2048 CUs + 2048 P^2.  Never reallocated, so a captured graph's launches keep a valid address.  The step runs its recurrences
-// on one stream; two cluster recurrences in flight at once on one device (two streams, or two host threads) would share granules
-// and are not supported.
+// on one stream.  Two cluster recurrences in flight at once on one device (two streams) would share granules AND wait for each
+// other's CUs (measured: 4.8 s per step until the bounded polls expire): cl_turn below orders launches from different streams
+// behind each other.  (Not inside a stream capture -- a captured step has one recurrence stream; two graphs that both hold cluster
+// recurrences must not be replayed side by side.)
 static unsigned long long* cl_exchange(int which, size_t granules)
 {
     static std::mutex mu;
@@ -350,6 +352,24 @@ static unsigned long long* cl_exchange(int which, size_t granules)
         b.second = cap;
     }
     return granules <= b.second ? b.first : nullptr;
+}
+
+// One cluster recurrence at a time per device: a launch waits for the previous launch's end (an event per device; a no-op when both
+// are on one stream).  `end` = false before the launch (wait), true after it (record).
+static int cl_turn(hipStream_t st, bool end)
+{
+    static std::mutex mu;
+    static std::map<int, std::pair<hipEvent_t, bool>> last;          // event, recorded at least once
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) return -4;
+    if (cs != hipStreamCaptureStatusNone) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -4;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = last[dev];
+    if (!e.first && hipEventCreateWithFlags(&e.first, hipEventDisableTiming) != hipSuccess) { e.first = nullptr; return -4; }
+    if (end) { e.second = true; return hipEventRecord(e.first, st) == hipSuccess ? 0 : -4; }
+    return (!e.second || hipStreamWaitEvent(st, e.first, 0) == hipSuccess) ? 0 : -4;
 }
 
 bool bilstm_cluster_ok(int B, int Nq, int H)
@@ -380,10 +400,11 @@ int launch_bilstm_cluster_fwd(hipStream_t st, float* G, const float* W4, const i
     const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * H * CL_BS;
     unsigned long long* xch = cl_exchange(0, gran);
     if (!xch) return -2;
+    if (cl_turn(st, false)) return -4;
     if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
     hipLaunchKernelGGL(bilstm_cluster_fwd_kernel, dim3(grid), dim3(256), lds, st, G, W4, len, B, Nq, H, P, nclus, Hout, Cs, xch);
     SMIN_LAUNCH_CHECK();
-    return 0;
+    return cl_turn(st, true);
 }
 
 int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G, const float* Cs, const float* Whh, const int* len, int B, int Nq, int H,
@@ -400,10 +421,11 @@ int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G
     const size_t gran = (size_t)cdiv(nclus, 8) * 8 * 2 * P * P * CL_U * CL_BS;
     unsigned long long* xch = cl_exchange(1, gran);
     if (!xch) return -2;
+    if (cl_turn(st, false)) return -4;
     if (P > 1 && hipMemsetAsync(xch, 0, gran * sizeof(unsigned long long), st) != hipSuccess) return -3;
     hipLaunchKernelGGL(bilstm_cluster_bwd_kernel, dim3(grid), dim3(256), lds, st, dHout, G, Cs, Whh, len, B, Nq, H, P, nclus, dG, xch);
     SMIN_LAUNCH_CHECK();
-    return 0;
+    return cl_turn(st, true);
 }
 
 }  // namespace smin
