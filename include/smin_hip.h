@@ -337,9 +337,10 @@ int smin_bilstm_layer_bwd(void* stream, const float* dHout, const float* X, cons
                           float* dX, float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
 /* The weights half in up to three independent pieces, each with its own part of ws (which: bit 0 = dWih_cat + dbias_cat, bit 1 =
  * dWhh[0], bit 2 = dWhh[1]; 7 = what smin_bilstm_layer_bwd's weights half does): pieces issued on different streams run side by
- * side behind the inputs half (they are the last kernels of a train step, models.py:46-62 backward). */
+ * side behind the inputs half (they are the last kernels of a train step, models.py:46-62 backward).
+ * dbias_cat2 (NULL to skip): a second copy of dbias_cat -- b_ih and b_hh have the same gradient and each needs memory of its own. */
 int smin_bilstm_layer_bwd_weights(void* stream, int which, const float* X, const float* Hout, int B, int Nq, int In, int H,
-                                  float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes);
+                                  float* dWih_cat, float* dbias_cat, float* dbias_cat2, float* dWhh, void* ws, size_t ws_bytes);
 
 /* The recurrences above run, for H a multiple of 32, as clusters of workgroups that keep W_hh in LDS and exchange h / dh through
  * tagged granules in global memory (csrc/bilstm_cluster.hip); every poll there is bounded.  Returns 1 once a poll has expired since
@@ -356,6 +357,15 @@ int smin_build_cells(void* stream, const uint8_t* mask, int B, int L, int all_ce
  * *status (device int32, cleared once by the caller) is set to 1 if the mask lists a different number of cells. */
 int smin_build_cells_n(void* stream, const uint8_t* mask, int B, int L, int all_cells, int n_expected,
                        int32_t* cells, int32_t* row_ptr, int32_t* cellmap, int32_t* status);
+
+/* What the train step derives from its masks and the boundary heads' parameters before its first real kernel, in one launch
+ * (main.py:141-160 hands the batch over as it comes from the dataset: byte masks): len32 [B] = words per query, qmf [B][Nq] /
+ * vmaskf [B][T] / lmf [B][L] = the masks as fp32, *count (device int64) = number of set cells of moment_mask [B][L][L],
+ * wb [3][D] / bb [3] = weights and biases of the start / end / "all" heads side by side (Localization, models.py:318-333; w, b:
+ * HOST arrays of three device pointers).  Masks: one byte per element.  acc: 16 bytes of device memory, zero on entry and on exit. */
+int smin_step_prologue(void* stream, const uint8_t* query_mask, const uint8_t* video_mask, const uint8_t* length_mask, const uint8_t* moment_mask,
+                       const float* const* w, const float* const* b, int B, int Nq, int T, int L, int D, int32_t* len32, float* qmf, float* vmaskf,
+                       float* lmf, float* wb, float* bb, int64_t* count, void* acc);
 
 /* ---- layout helpers: dense (B,L,L,W) <-> packed [N][W] rows (W floats per cell). */
 int smin_pack_cells(void* stream, const float* dense, const int32_t* cells, int N, int L, int W, float* packed);

@@ -1061,8 +1061,10 @@ def test_step_helpers_through_the_c_abi(dev):
         args = (ptr(xq), ptr(Ho), ptr(G), ptr(Cs), ptr(WihT), ptr(Whh), ptr(length), B, Nq, In, Hh)
         if split == "pieces":                                    # inputs half, then the weights half piece by piece in another order
             call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), None, None, None, ptr(ws), ws.numel())
+            dbi2 = torch.full_like(dbi, 7.0)
             for which in (4, 1, 2):
-                call("smin_bilstm_layer_bwd_weights", stream(), which, ptr(xq), ptr(Ho), B, Nq, In, Hh, ptr(dWih), ptr(dbi), ptr(dWhh), ptr(ws), ws.numel())
+                call("smin_bilstm_layer_bwd_weights", stream(), which, ptr(xq), ptr(Ho), B, Nq, In, Hh, ptr(dWih), ptr(dbi), ptr(dbi2), ptr(dWhh), ptr(ws), ws.numel())
+            assert torch.equal(dbi, dbi2)
         elif split:
             call("smin_bilstm_layer_bwd", stream(), ptr(dHo), *args, ptr(dX), None, None, None, ptr(ws), ws.numel())
             assert float(dWih.min()) == 7.0 and float(dWhh.min()) == 7.0
@@ -1251,6 +1253,34 @@ def test_layout_build_kernels(dev):
         assert got_all.N == B * L * L and not got_all.all_valid
         for name in ("cells", "row_ptr", "cellmap"):
             assert torch.equal(getattr(got_all, name).cpu(), getattr(ref_all, name)), (B, L, name, "all")
+
+
+def test_step_prologue_kernel(dev):
+    """smin_step_prologue (the masks as fp32, query lengths, valid-cell count, the boundary heads' parameters side by side: one
+    launch) against the torch formulation, twice in a row (the counting words must come back to zero), ragged sizes."""
+    import models
+    from vml_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(21)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    for (B, Nq, T, L, D) in [(3, 5, 7, 6, 12), (64, 20, 256, 64, 512), (2, 1, 1030, 130, 4)]:
+        qm = (torch.rand(B, Nq, generator=g) > 0.3).to(torch.uint8).to(dev)
+        vm = (torch.rand(B, T, 1, generator=g) > 0.3).to(torch.uint8).to(dev)
+        lm = (torch.rand(B, L, generator=g) > 0.3).to(dev)
+        mm = (torch.rand(B, L, L, generator=g) > 0.6).to(dev)
+        w = [torch.randn(D, generator=g).to(dev) for _ in range(3)]
+        b = [torch.randn(1, generator=g).to(dev) for _ in range(3)]
+        for rep in range(2):
+            len32 = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            qmf, vmf, lmf = torch.full((B, Nq), 7.0, device=dev), torch.full((B * T,), 7.0, device=dev), torch.full((B, L), 7.0, device=dev)
+            wb, bb, count = torch.full((3, D), 7.0, device=dev), torch.full((3,), 7.0, device=dev), torch.full((1,), -1, dtype=torch.int64, device=dev)
+            import ctypes
+            arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            call("smin_step_prologue", stream(), ptr(qm), ptr(vm), ptr(lm), ptr(mm), arr(w), arr(b), B, Nq, T, L, D, ptr(len32), ptr(qmf), ptr(vmf), ptr(lmf), ptr(wb),
+                 ptr(bb), ptr(count), ptr(acc))
+            assert torch.equal(len32, qm.sum(1).to(torch.int32)) and int(count) == int(mm.sum())
+            assert torch.equal(qmf, qm.float()) and torch.equal(vmf, vm.reshape(-1).float()) and torch.equal(lmf, lm.float())
+            assert torch.equal(wb, torch.stack(w)) and torch.equal(bb, torch.cat(b))
+            assert int(acc.abs().sum()) == 0
 
 
 # ---------------------------------------------------------------- the captured step (training.CapturedStep)

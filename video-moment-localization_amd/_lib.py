@@ -85,7 +85,8 @@ SIGNATURES = {
     "smin_sentence_feature_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_bilstm_layer_bwd_workspace_bytes": [_i] * 4,
     "smin_bilstm_layer_bwd": [_vp] * 9 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
-    "smin_bilstm_layer_bwd_weights": [_vp, _i, _vp, _vp] + [_i] * 4 + [_vp] * 3 + [_vp, _sz],
+    "smin_step_prologue": [_vp] * 7 + [_i] * 5 + [_vp] * 8,
+    "smin_bilstm_layer_bwd_weights": [_vp, _i, _vp, _vp] + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
 }
 _RESTYPE = {"smin_target_arch": ctypes.c_char_p, "smin_workspace_bytes": _sz,
             "smin_content_attn_bwd_workspace_bytes": _sz, "smin_linear_rows_bwd_workspace_bytes": _sz,
@@ -155,14 +156,14 @@ def load_torch():
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32/int32 HIP tensor (None -> NULL)."""
+    """Device pointer of a contiguous HIP tensor of one of the element types the C ABI takes (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise SminHipError("the SMIN hot path runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
     if not t.is_contiguous():
         raise SminHipError("internal error: non-contiguous tensor handed to the C ABI")
-    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float64, torch.bool):
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float64, torch.bool, torch.int64):
         raise SminHipError(f"unsupported dtype {t.dtype}")
     return ctypes.c_void_p(t.data_ptr())
 

@@ -373,14 +373,16 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
         }
     }
     if (!dWih_cat) return 0;
-    return smin_bilstm_layer_bwd_weights(stream, 7, X, Hout, B, Nq, In, H, dWih_cat, dbias_cat, dWhh, ws, ws_bytes);
+    return smin_bilstm_layer_bwd_weights(stream, 7, X, Hout, B, Nq, In, H, dWih_cat, dbias_cat, nullptr, dWhh, ws, ws_bytes);
 }
 
 // The weights half in up to three independent pieces (which: bit 0 = dWih_cat + dbias_cat, bit 1 = dWhh[0], bit 2 = dWhh[1]), each
 // with its own part of ws: issued on three streams they run side by side -- they are the last kernels of a train step, one after
 // the other they were ~0.2 ms of seven short launches behind the last recurrence.
+// dbias_cat2 (NULL to skip): a second copy of dbias_cat (nn.LSTM has two bias vectors per direction with the same gradient; each
+// parameter's .grad needs memory of its own).
 extern "C" int smin_bilstm_layer_bwd_weights(void* stream, int which, const float* X, const float* Hout, int B, int Nq, int In, int H,
-                                             float* dWih_cat, float* dbias_cat, float* dWhh, void* ws, size_t ws_bytes)
+                                             float* dWih_cat, float* dbias_cat, float* dbias_cat2, float* dWhh, void* ws, size_t ws_bytes)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(In % 4 == 0 && H % 4 == 0 && H >= 4 && H <= 256 && B >= 1 && Nq >= 1 && which >= 1 && which <= 7);
@@ -397,14 +399,21 @@ extern "C" int smin_bilstm_layer_bwd_weights(void* stream, int which, const floa
     if (which & 1) {
         SMIN_REQUIRE(dWih_cat != nullptr && dbias_cat != nullptr);
         rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
-        rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1); if (rc) return rc;
+        rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1, dbias_cat2); if (rc) return rc;
+    }
+    if ((which & 6) == 6) {                                            // both directions on this stream: one shift launch
+        const size_t tot = (size_t)2 * R * H;
+        hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, 0, 2);
+        SMIN_LAUNCH_CHECK();
     }
     for (int d = 0; d < 2; ++d) {
         if (!(which & (2 << d))) continue;
         SMIN_REQUIRE(dWhh != nullptr);
-        const size_t tot = (size_t)R * H;
-        hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, d, 1);
-        SMIN_LAUNCH_CHECK();
+        if ((which & 6) != 6) {
+            const size_t tot = (size_t)R * H;
+            hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, d, 1);
+            SMIN_LAUNCH_CHECK();
+        }
         float* sl = slab2 + (size_t)d * sp2 * H4 * H;
         rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, PlainMat{Hprev + (size_t)d * R * H, H}, sl, (float*)nullptr, R, H4, H, sp2);
         if (rc) return rc;

@@ -967,6 +967,6 @@ static inline int launch_gemm_tn(hipStream_t st, const AM& am, const BM_& bm, fl
 // out[idx] = sum_z slab[z][idx]   (fixed order: deterministic)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int P);
 int launch_reduce_slabs(hipStream_t st, const float* slab, float* out, int n, int P);
-int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA, const float* slabB, float* outB, int nB, int P);
+int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA, const float* slabB, float* outB, int nB, int P, float* outB2 = nullptr);
 
 }  // namespace smin

@@ -122,3 +122,75 @@ extern "C" int smin_build_cells_n(void* stream, const uint8_t* mask, int B, int 
     SMIN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------- the step's mask prologue
+// Everything the train step derives from its four masks and the localization head's parameters before its first real kernel, in
+// one launch (as torch calls: two reductions, four conversions, a stack and a concatenation -- eight launches in front of the
+// query encoder, which opens the step's critical path):
+//   len32[b] = number of words of query b, qmf / vmaskf / lmf = the masks as fp32, count = number of valid cells (moment_mask),
+//   wb [3][D] / bb [3] = the three boundary heads' weights and biases side by side (Localization, models.py:318-333).
+namespace smin {
+struct PrologueArgs {
+    const unsigned char *qmask, *vmask, *lmask, *mmask;
+    const float* w[3]; const float* b[3];
+    int B, Nq, T, L, D;
+    int* len32; float *qmf, *vmaskf, *lmf, *wb, *bb;
+    long long* count; unsigned long long* acc;                   // acc[0] = running sum, acc[1] = ticket (both zero between launches)
+};
+
+__global__ __launch_bounds__(256)
+void prologue_kernel(PrologueArgs a)
+{
+    const size_t nq = (size_t)a.B * a.Nq, nv = (size_t)a.B * a.T, nl = (size_t)a.B * a.L, nw = (size_t)3 * a.D, nm = (size_t)a.B * a.L * a.L;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    for (size_t i = tid; i < nq; i += nth) a.qmf[i] = a.qmask[i] ? 1.f : 0.f;
+    for (size_t i = tid; i < nv; i += nth) a.vmaskf[i] = a.vmask[i] ? 1.f : 0.f;
+    for (size_t i = tid; i < nl; i += nth) a.lmf[i] = a.lmask[i] ? 1.f : 0.f;
+    for (size_t i = tid; i < nw; i += nth) { const int h = (int)(i / a.D); a.wb[i] = (h == 0 ? a.w[0] : h == 1 ? a.w[1] : a.w[2])[i - (size_t)h * a.D]; }
+    if (tid < 3) a.bb[tid] = (tid == 0 ? a.b[0] : tid == 1 ? a.b[1] : a.b[2])[0];
+    for (size_t b = tid; b < (size_t)a.B; b += nth) {
+        int s = 0;
+        for (int q = 0; q < a.Nq; ++q) s += a.qmask[b * a.Nq + q] ? 1 : 0;
+        a.len32[b] = s;
+    }
+    // valid cells: integer sums (any order gives the same count); the last workgroup to arrive publishes the total and clears the words
+    unsigned int part = 0;
+    for (size_t i = tid; i < nm; i += nth) part += a.mmask[i] ? 1u : 0u;
+    __shared__ unsigned int red[256];
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.acc[0], (unsigned long long)red[0]);
+        __threadfence();
+        const unsigned long long t = atomicAdd(&a.acc[1], 1ull);
+        if (t == (unsigned long long)gridDim.x - 1) {
+            __threadfence();
+            a.count[0] = (long long)atomicAdd(&a.acc[0], 0ull);
+            atomicExch(&a.acc[0], 0ull);
+            atomicExch(&a.acc[1], 0ull);
+        }
+    }
+}
+}  // namespace smin
+
+// masks: one byte per element (bool / uint8), non-zero = set.  w / b: HOST arrays of the three heads' weight [D] and bias [1] device
+// pointers.  count: device int64; acc: two device words that are zero on entry (the launch leaves them zero).
+extern "C" int smin_step_prologue(void* stream, const uint8_t* query_mask, const uint8_t* video_mask, const uint8_t* length_mask, const uint8_t* moment_mask,
+                                  const float* const* w, const float* const* b, int B, int Nq, int T, int L, int D, int32_t* len32, float* qmf, float* vmaskf,
+                                  float* lmf, float* wb, float* bb, int64_t* count, void* acc)
+{
+    SMIN_REQUIRE(B >= 1 && Nq >= 1 && T >= 1 && L >= 1 && D >= 1 && acc != nullptr && count != nullptr);
+    PrologueArgs a;
+    a.qmask = query_mask; a.vmask = video_mask; a.lmask = length_mask; a.mmask = moment_mask;
+    for (int h = 0; h < 3; ++h) { a.w[h] = w[h]; a.b[h] = b[h]; }
+    a.B = B; a.Nq = Nq; a.T = T; a.L = L; a.D = D;
+    a.len32 = len32; a.qmf = qmf; a.vmaskf = vmaskf; a.lmf = lmf; a.wb = wb; a.bb = bb;
+    a.count = reinterpret_cast<long long*>(count); a.acc = reinterpret_cast<unsigned long long*>(acc);
+    const size_t work = (size_t)B * L * L > (size_t)B * T ? (size_t)B * L * L : (size_t)B * T;
+    int grid = (int)((work + 256 * 8 - 1) / (256 * 8));
+    grid = grid < 1 ? 1 : grid > 256 ? 256 : grid;
+    hipLaunchKernelGGL(prologue_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}

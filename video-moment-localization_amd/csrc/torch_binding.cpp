@@ -175,6 +175,17 @@ Tensor layout_status(const at::Device& dev)
     return t;
 }
 
+// the two device words smin_step_prologue counts with (zero between launches)
+Tensor prologue_words(const at::Device& dev)
+{
+    static std::mutex mu;
+    static std::map<int, Tensor> st;
+    std::lock_guard<std::mutex> lk(mu);
+    Tensor& t = st[(int)dev.index()];
+    if (!t.defined()) t = at::zeros({2}, at::TensorOptions().dtype(at::kLong).device(dev));
+    return t;
+}
+
 // ---------------------------------------------------------------- gradient exchange inside the node (data parallel)
 // With the whole model as one autograd node torch DDP sees every gradient only when the node returns: its all-reduce would start
 // after the backward pass.  Instead the node hands each group of finished gradient buffers to the process group itself
@@ -679,7 +690,9 @@ struct LossNode : torch::autograd::Function<LossNode> {
                      &ya = sv[11], &lm = sv[12], &part = sv[13];
         const int B = i32(ps.size(0)), L = i32(ps.size(1));
         Tensor dloss = cont(fl(g[0].reshape({1})));
-        Tensor dpm = at::empty_like(pm), dps = at::empty_like(ps), dpe = at::empty_like(pe), dpa = at::empty_like(pa);
+        // the three score gradients are rows of one buffer: the model's node takes them as they are (no gather)
+        Tensor dpm = at::empty_like(pm), d3 = at::empty({3, (int64_t)B, (int64_t)L}, ps.options());
+        Tensor dps = d3[0], dpe = d3[1], dpa = d3[2];
         auto u8 = [](const Tensor& t) { return static_cast<const uint8_t*>(t.const_data_ptr()); };
         SMIN_CK(smin_loss_bwd(cur(), fp(dloss), fp(part), fp(pm), u8(ym), fp(sm), u8(mm), fp(ps), u8(ys), fp(ss), fp(pe), u8(ye), fp(se), fp(pa), u8(ya), u8(lm), B, L,
                               fpm(dpm), fpm(dps), fpm(dpe), fpm(dpa)));
@@ -823,25 +836,47 @@ struct SminCore : torch::autograd::Function<SminCore> {
             }
             products_ready = mark(prep);
         }
-        st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});      // (two tiny torch launches, main stream)
-        bb = at::cat({loc[3], loc[5], loc[7]});
-
-        // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued -- unless the
-        // caller already knows it (flags >> 16 = count + 1; a captured step: nothing inside may wait for the device)
+        // ---- masks as fp32, query lengths, the cell count, the boundary heads' parameters side by side: one launch (csrc/layout.hip);
+        // as torch calls (masks that are not one byte per element) eight launches in front of the query encoder
         const int64_t n_known = (flags >> 16) - 1;
-        Tensor mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
-        Tensor host_n;
-        if (n_known < 0) {
-            host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-            host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+        Tensor qm = query_mask.reshape({Bq, -1});
+        auto bytes = [](const Tensor& t) { return t.element_size() == 1 && t.is_contiguous(); };
+        const bool fast_prologue = bytes(video_mask) && bytes(qm) && bytes(length_mask) && bytes(moment_mask) && qm.size(1) == maxq && video_mask.numel() == Bq * Tn &&
+                                   length_mask.numel() == Bq * L && moment_mask.numel() == Bq * L * L;
+        Tensor mm, host_n, qmf, lmf;
+        if (fast_prologue) {
+            st.wb = at::empty({3, (int64_t)D}, opt); bb = at::empty({3}, opt);
+            st.len32 = at::empty({Bq}, opt.dtype(at::kInt));
+            qmf = at::empty({Bq, maxq}, opt); lmf = at::empty({Bq, L}, opt); st.vmaskf = at::empty({Bq * Tn}, opt);
+            Tensor count = at::empty({1}, opt.dtype(at::kLong));
+            const float* w3[3] = {fp(loc[2]), fp(loc[4]), fp(loc[6])};
+            const float* b3[3] = {fp(loc[3]), fp(loc[5]), fp(loc[7])};
+            auto u8 = [](const Tensor& t) { return static_cast<const uint8_t*>(t.const_data_ptr()); };
+            SMIN_CK(smin_step_prologue(cur(), u8(qm), u8(video_mask), u8(length_mask), u8(moment_mask), w3, b3, B, Nq, Ti, Li, D, st.len32.data_ptr<int32_t>(), fpm(qmf),
+                                       fpm(st.vmaskf), fpm(lmf), fpm(st.wb), fpm(bb), count.data_ptr<int64_t>(), prologue_words(dev).data_ptr()));
+            mm = moment_mask;
+            if (n_known < 0) {
+                host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+                host_n.copy_(count, /*non_blocking=*/true);
+            }
+        } else {
+            st.wb = at::stack({loc[2].view({D}), loc[4].view({D}), loc[6].view({D})});
+            bb = at::cat({loc[3], loc[5], loc[7]});
+            // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued -- unless the
+            // caller already knows it (flags >> 16 = count + 1; a captured step: nothing inside may wait for the device)
+            mm = moment_mask.scalar_type() == at::kBool ? moment_mask : moment_mask.ne(0);
+            if (n_known < 0) {
+                host_n = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+                host_n.copy_(mm.sum().reshape({1}), /*non_blocking=*/true);
+            }
+            st.len32 = qm.sum(1).to(at::kInt);
+            st.vmaskf = cont(fl(video_mask.reshape({Bq * Tn})));
+            qmf = cont(fl(qm)); lmf = cont(fl(length_mask));
         }
         hipEvent_t count_ready = next_event();
         TORCH_CHECK(hipEventRecord(count_ready, curs.stream()) == hipSuccess, "hipEventRecord failed");
 
         // ---- backbone (models.py:38-83): BiLSTM x 2, sentence feature, fused video encoder
-        Tensor qm = query_mask.reshape({Bq, -1});
-        Tensor length = qm.sum(1);
-        st.len32 = length.to(at::kInt);
         Tensor x = cont(query_features);
         for (int layer = 0; layer < 2; ++layer) {
             const Tensor* w = &all[P_LSTM + 8 * layer];
@@ -866,7 +901,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
         fw = fw.contiguous();
         Tensor fs = at::empty({Bq, 2 * H}, opt);                                    // [h_fwd at the last word | h_bwd at the first word]
         SMIN_CK(smin_sentence_feature_fwd(cur(), fp(fw), ip(st.len32), B, i32(fw.size(1)), i32(H), fpm(fs)));
-        st.vx = cont(video_features); st.vmaskf = cont(fl(video_mask.reshape({Bq * Tn})));
+        st.vx = cont(video_features);
         st.fv = at::empty({Bq, T, (int64_t)D}, opt);
         Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
         SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), fp(fs), B, Ti, i32(st.vx.size(2)), D, fpm(st.fv), fpm(f)));
@@ -891,7 +926,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
                                            cellmap.data_ptr<int32_t>(), layout_status(dev).data_ptr<int32_t>()));
             layout_ready = mark(prep);
         }
-        Tensor qmf = cont(fl(qm)), lmf = cont(fl(length_mask));
         st.f = f; st.fw = fw; st.fs = fs; st.qmf = qmf; st.lmf = lmf; st.cells = cells; st.row_ptr = row_ptr; st.cellmap = cellmap;
 
         // ---- word-side operands on the second stream, behind the backbone; the main stream needs them at the first attention only
@@ -1020,7 +1054,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
         for (auto& p : all) flat.push_back(p);
         ctx->save_for_backward(flat);
         ctx->saved_data["d"] = std::vector<int64_t>{N, T, L, C, nl, flags, H, Nq_in, prep_kernel ? 1 : 0};
-        return {pm, psea};
+        // ps / pe / pa leave as three outputs of the node (rows of one buffer), not as selections of one output: the selections'
+        // backward nodes cost three zero fills, three copies and two adds between the loss and this node's backward
+        return {pm, psea[0], psea[1], psea[2]};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g)
@@ -1073,7 +1109,20 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
         // ---- Localization
         const Tensor& bu_last = st.layer[nl - 1].bu;
-        Tensor dpm = g[0].defined() ? cont(g[0]) : at::zeros_like(st.pm), dpsea = g[1].defined() ? cont(g[1]) : at::zeros_like(st.psea);
+        Tensor dpm = g[0].defined() ? cont(g[0]) : at::zeros_like(st.pm), dpsea;
+        {
+            // the three score gradients as one (3, B, L) buffer: the library's loss hands over rows of one buffer (used as it is);
+            // anything else is gathered
+            const int64_t BL = (int64_t)B * L;
+            bool rows = g[1].defined() && g[2].defined() && g[3].defined();
+            for (int h = 1; rows && h <= 3; ++h) rows = g[h].scalar_type() == at::kFloat && g[h].is_contiguous() && g[h].numel() == BL;
+            if (rows && fp(g[2]) == fp(g[1]) + BL && fp(g[3]) == fp(g[1]) + 2 * BL) dpsea = g[1];
+            else {
+                std::vector<Tensor> parts;
+                for (int h = 1; h <= 3; ++h) parts.push_back(g[h].defined() ? fl(g[h]).reshape({B, L}) : at::zeros({B, L}, opt));
+                dpsea = at::stack(parts);
+            }
+        }
         Tensor dfm = at::empty({N, D}, opt), dfb_next = at::empty({B, L, D}, opt);
         std::vector<Tensor> loc_bufs;
         {
@@ -1448,20 +1497,26 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 Tensor wsl = own(smin_bilstm_layer_bwd_workspace_bytes(B, i32(Nq_in), In, Hh));
                 SMIN_CK(smin_bilstm_layer_bwd(cur(), fp(dH), fp(ls.x), fp(ls.Hout), fp(ls.G), fp(ls.Cs), fp(WihT[layer]), fp(ls.Whh), ip(st.len32), B, i32(Nq_in), In, Hh,
                                               fpm(dX), nullptr, nullptr, nullptr, wsl.data_ptr(), (size_t)wsl.numel()));
-                // the weight gradients: three independent pieces; the last layer's (nothing else is left to run by then) on three streams
+                // the weight gradients: three independent pieces; the last layer's (nothing else is left to run by then) on three streams,
+                // pieces that share a stream in one call.  b_ih and b_hh get the same gradient in two tensors (dbias2: one tensor handed
+                // to both made autograd clone it, a launch per bias at the very end of the step).
+                Tensor dbias2 = at::empty({8 * H}, opt);
+                lstm_bufs.push_back(dbias2);
                 HStream piece[3] = {bstr, bstr, bstr};
                 if (layer == 0 && bstr == wordst && tail != curs) { piece[1] = tail; piece[2] = wstr; }
                 for (int pc = 0; pc < 3; ++pc) {
-                    if (pc == 0 || piece[pc] != piece[pc - 1]) wait_stream(piece[pc], curs);
+                    int which = 1 << pc;
+                    while (pc + 1 < 3 && piece[pc + 1] == piece[pc]) which |= 1 << ++pc;
+                    wait_stream(piece[pc], curs);
                     StreamScope sc(piece[pc]);
-                    SMIN_CK(smin_bilstm_layer_bwd_weights(cur(), 1 << pc, fp(ls.x), fp(ls.Hout), B, i32(Nq_in), In, Hh, fpm(dWih), fpm(dbias), fpm(dWhh), wsl.data_ptr(),
-                                                          (size_t)wsl.numel()));
+                    SMIN_CK(smin_bilstm_layer_bwd_weights(cur(), which, fp(ls.x), fp(ls.Hout), B, i32(Nq_in), In, Hh, fpm(dWih), fpm(dbias), fpm(dbias2), fpm(dWhh),
+                                                          wsl.data_ptr(), (size_t)wsl.numel()));
                 }
                 if (dX.defined()) keep.push_back(dX);
                 const int64_t H4 = 4 * H;
                 Tensor* o = &dbb[P_LSTM + 8 * layer];
-                Tensor db_f = dbias.slice(0, 0, H4), db_r = dbias.slice(0, H4);
-                o[0] = dWih.slice(0, 0, H4); o[1] = dWhh[0]; o[2] = db_f; o[3] = db_f; o[4] = dWih.slice(0, H4); o[5] = dWhh[1]; o[6] = db_r; o[7] = db_r;
+                o[0] = dWih.slice(0, 0, H4); o[1] = dWhh[0]; o[2] = dbias.slice(0, 0, H4); o[3] = dbias2.slice(0, 0, H4);
+                o[4] = dWih.slice(0, H4); o[5] = dWhh[1]; o[6] = dbias.slice(0, H4); o[7] = dbias2.slice(0, H4);
                 dH = dX;
             }
         }
@@ -1511,8 +1566,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
                               ((cfg.size() >= 14 && cfg[13] != 0) ? SminCore::F_GRAD_SYNC : 0) |
                               ((cfg.size() >= 15 && cfg[14] >= 0) ? ((cfg[14] + 1) << 16) : 0);      // cfg[14]: the number of valid cells, when the caller knows it
         auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
-        Tensor psea = out[1];
-        return std::make_tuple(out[0], psea[0], psea[1], psea[2]);
+        return std::make_tuple(out[0], out[1], out[2], out[3]);
     }
 
     // ---- layout, part 1: the cell count leaves for the host now and is waited for after the backbone is queued

@@ -63,12 +63,14 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __res
 }
 
 // the weight and bias slabs of one contraction in one launch (same fixed association as reduce_slabs_kernel)
+// (outB2: optional second copy of the bias result -- two parameters that receive the same gradient each get a tensor of their own)
 __global__ void reduce_slabs2_kernel(const float* __restrict__ slabA, float* __restrict__ outA, int nA,
-                                     const float* __restrict__ slabB, float* __restrict__ outB, int nB, int P)
+                                     const float* __restrict__ slabB, float* __restrict__ outB, int nB, int P, float* __restrict__ outB2)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const float* slab = slabA; float* out = outA; int n = nA;
-    if (idx >= nA) { idx -= nA; slab = slabB; out = outB; n = nB; }
+    float* out2 = nullptr;
+    if (idx >= nA) { idx -= nA; slab = slabB; out = outB; n = nB; out2 = outB2; }
     if (idx >= n) return;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int z = 0;
@@ -77,13 +79,15 @@ __global__ void reduce_slabs2_kernel(const float* __restrict__ slabA, float* __r
         for (int u = 0; u < 8; ++u) s[u] += slab[(size_t)(z + u) * n + idx];
     }
     for (; z < P; ++z) s[0] += slab[(size_t)z * n + idx];
-    out[idx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    out[idx] = v;
+    if (out2) out2[idx] = v;
 }
 
-int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA, const float* slabB, float* outB, int nB, int P)
+int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA, const float* slabB, float* outB, int nB, int P, float* outB2)
 {
     if (nA <= 0 || nB <= 0 || !outB) return launch_reduce_slabs(st, slabA, outA, nA, P);
-    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3(cdiv(nA + nB, 256)), dim3(256), 0, st, slabA, outA, nA, slabB, outB, nB, P);
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3(cdiv(nA + nB, 256)), dim3(256), 0, st, slabA, outA, nA, slabB, outB, nB, P, outB2);
     SMIN_LAUNCH_CHECK();
     return 0;
 }
