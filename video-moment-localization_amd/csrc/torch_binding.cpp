@@ -768,7 +768,7 @@ Tensor sum_list(const std::vector<Tensor>& ts)
 }
 
 struct SminCore : torch::autograd::Function<SminCore> {
-    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4, F_BF16_OPERANDS = 8, F_GRAD_SYNC = 16 };
+    enum { F_OVERLAP_BOUNDARY = 1, F_OVERLAP_PREP = 2, F_ASYNC_WEIGHTS = 4, F_BF16_OPERANDS = 8, F_GRAD_SYNC = 16, F_NO_TAIL_SPLIT = 32 };
     enum { N_FIXED = 13 };          // forward arguments ahead of the parameter list (tensors and scalars alike take one gradient slot)
 
     static variable_list forward(AutogradContext* ctx, Tensor video_features, Tensor video_mask, Tensor query_features, Tensor query_mask, Tensor length_mask,
@@ -1317,7 +1317,13 @@ struct SminCore : torch::autograd::Function<SminCore> {
         //   main   : layer 0's gate backward (already queued above), the proposal map's gradient -> df, video encoder, LSTM layers
         // (before: the first two waited for the gate backward and the clip-window pass sat between it and the proposal map on the
         //  main stream -- 0.5 ms longer, tools/gantt.sh)
-        static const bool tail_split = !(std::getenv("SMIN_TAIL_SPLIT") && std::atoi(std::getenv("SMIN_TAIL_SPLIT")) == 0);   // 0: the round-2 placement (A/B)
+        // F_NO_TAIL_SPLIT / SMIN_TAIL_SPLIT=0: the round-2 placement (words on the boundary stream, clip-window gradients on the main
+        // stream).  training.CapturedStep asks for it: a replayed graph pays for the extra streams (tacos.yml captured: 3.5 ms/step
+        // once the process has used them, 2.5 without; eager 2.2) -- and never inside a stream capture.
+        static const bool tail_split_env = !(std::getenv("SMIN_TAIL_SPLIT") && std::atoi(std::getenv("SMIN_TAIL_SPLIT")) == 0);
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        TORCH_CHECK(hipStreamIsCapturing(curs.stream(), &capture) == hipSuccess, "hipStreamIsCapturing failed");
+        const bool tail_split = tail_split_env && !(flags & F_NO_TAIL_SPLIT) && capture == hipStreamCaptureStatusNone;
         HStream tail = (flags & F_OVERLAP_PREP) ? side_stream(dev.index()) : curs;
         HStream wordst = !(flags & F_OVERLAP_PREP) ? curs : tail_split ? side_stream(dev.index(), 1) : tail;
         HStream cw = tail_split ? tail : curs;                                      // stream of the clip-window gradients
@@ -1551,7 +1557,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
                 " columns for ", query_features.size(1), " words (max_query_length ", cfg[6], ")");
     if (query_mask.size(1) < cfg[6]) query_mask = at::constant_pad_nd(query_mask, {0, cfg[6] - query_mask.size(1)}, 0);
     TORCH_CHECK(video_features.is_cuda(), "smin_forward runs on a HIP device only (there is no CPU fallback)");
-    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core, async_weights, bf16_operand_storage)]");
+    TORCH_CHECK(cfg.size() >= 10, "smin_forward: cfg = [T, L, C, D, dl, layers, max_query_length, H, overlap_boundary, overlap_prep(, fused_core, async_weights, bf16_operand_storage, grad_sync, known_cell_count or -1, tail_split)]");
     const int64_t T = cfg[0], L = cfg[1], C = cfg[2], D = cfg[3], nl = cfg[5], maxq = cfg[6], H = cfg[7];
     const bool overlap_boundary = cfg[8] != 0, overlap_prep = cfg[9] != 0;
     TORCH_CHECK((int64_t)prm.size() == P_LAYER0 + nl * L_COUNT + 8, "smin_forward: expected ", P_LAYER0 + nl * L_COUNT + 8, " parameters, got ", prm.size());
@@ -1564,6 +1570,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> smin_forward(const Tensor& video_feat
         const int64_t flags = (overlap_boundary ? SminCore::F_OVERLAP_BOUNDARY : 0) | (overlap_prep ? SminCore::F_OVERLAP_PREP : 0) |
                               ((cfg.size() >= 12 && cfg[11] != 0) ? SminCore::F_ASYNC_WEIGHTS : 0) | ((cfg.size() >= 13 && cfg[12] != 0) ? SminCore::F_BF16_OPERANDS : 0) |
                               ((cfg.size() >= 14 && cfg[13] != 0) ? SminCore::F_GRAD_SYNC : 0) |
+                              ((cfg.size() >= 16 && cfg[15] == 0) ? SminCore::F_NO_TAIL_SPLIT : 0) |
                               ((cfg.size() >= 15 && cfg[14] >= 0) ? ((cfg[14] + 1) << 16) : 0);      // cfg[14]: the number of valid cells, when the caller knows it
         auto out = SminCore::apply(video_features, video_mask, query_features, query_mask, length_mask, moment_mask, T, L, C, nl, maxq, H, flags, prm);
         return std::make_tuple(out[0], out[1], out[2], out[3]);

@@ -426,6 +426,8 @@ class SMIN(nn.Module):
     async_weights = True           # ... whose weight-gradient contractions run on a low-priority stream of their own
     known_cell_count = None        # number of valid cells of the next batches' moment_mask, when the caller knows it: the forward then
                                    # asks the device nothing (training.CapturedStep); a wrong value is flagged, see csrc/layout.hip
+    tail_split = True              # the backward's closing chains on streams of their own (torch_binding.cpp "the tail"); training.CapturedStep
+                                   # turns it off: a process that has used the extra streams replays its graphs ~1 ms/step slower
     grad_sync = False              # data parallel: the one-node backward averages its gradients over the process group itself, group by
                                    # group as they become final (set by distributed.wrap; torch_binding.cpp GradSync)
     bf16_operand_storage = True    # under set_gemm_mode("bf16"): tensors that only feed contractions are stored as bf16 (no bit of the step changes)
@@ -594,7 +596,7 @@ class SMIN(nn.Module):
             cfg = [self.T, self.L, self.C, self.D, self.dl, len(self.smis), self.max_query_length, self.lstm_hidden_size,
                    int(self.overlap_boundary), int(self.overlap_prep and (self._streams_allowed("torch") or self._prep_is_library_code())), int(self.fused_core),
                    int(self.async_weights), int(self.bf16_operand_storage), int(self.grad_sync and torch.is_grad_enabled()),
-                   -1 if self.known_cell_count is None else int(self.known_cell_count)]
+                   -1 if self.known_cell_count is None else int(self.known_cell_count), int(self.tail_split)]
             return _lib.load_torch().smin_forward(video_features, video_mask, query_features, query_mask, length_mask, moment_mask,
                                                   self._native_params(), cfg)
         pending = CellLayout.begin(moment_mask)                    # work is driven by moment_mask (SURVEY 8a-0 caveat)
