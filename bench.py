@@ -313,9 +313,9 @@ def main():
         ws = torch.empty(libc.smin_workspace_bytes(N, B, 4, D, 4, 1), dtype=torch.uint8, device=dev)
         fns = {"moment_fwd": lambda: call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fm_), ptr(fb_), ptr(lay.cells), N, B, L, D, ptr(W), ptr(bvec), ptr(mu), ptr(x1)),
                "moment_dx": lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb_), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D,
-                                         ptr(WT), ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1)),
+                                         ptr(WT), ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1), None),
                "moment_dw": lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb_), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D,
-                                         ptr(WT), None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1))}
+                                         ptr(WT), None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1), None)}
         for f in fns.values():                                  # warm-up of all three
             for _ in range(3):
                 f()

@@ -177,7 +177,8 @@ int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, co
                          float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
                          int all_valid /* 1: every listed cell has m == 1 (mask-driven list): skips the mask lookups */,
                          const float* dfcmean_acc /* nullable [N][D]: added into dfcmean (a second consumer of fcmean) */,
-                         const float* x1 /* nullable: the pair product saved by smin_moment_unit_fwd */);
+                         const float* x1 /* nullable: the pair product saved by smin_moment_unit_fwd */,
+                         const float* dfb_acc /* nullable [B][L][D]: added into dfb (another consumer's gradient of f_b) */);
 /* The same three with the pair product stored as bf16 (uint16_t bit patterns, round to nearest even), x1h [N][D]: half the bytes of the
  * largest saved tensor of a layer.  Under smin_set_gemm_mode(2) -- where every contraction rounds its operands to bf16 as it loads them --
  * the results equal the fp32-storage calls bit for bit; in the other modes the product loses its low bits.  all_valid must be 1. */
@@ -187,7 +188,7 @@ int smin_moment_unit_fwd_x1h(void* stream, const float* fcmean, const float* fm,
 int smin_moment_unit_bwd_x1h(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                              const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                              float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes,
-                             int all_valid, const float* dfcmean_acc, const uint16_t* x1h);
+                             int all_valid, const float* dfcmean_acc, const uint16_t* x1h, const float* dfb_acc);
 
 /* ---- Localization.forward (models.py:335-344): score heads.
  *   pm [B][L][L] dense, zero-filled outside the cell list;  wb [3][D], bb [3] = (ps, pe, pa) heads;

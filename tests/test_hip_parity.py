@@ -987,7 +987,7 @@ def test_step_helpers_through_the_c_abi(dev):
         dfc, dfb, dW, db = torch.full((N, D), 7.0, device=dev), torch.full((B, L, D), 7.0, device=dev), torch.full((D, 2 * D), 7.0, device=dev), torch.full((D,), 7.0, device=dev)
         call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D, ptr(WT),
              ptr(dfc) if want_in else None, ptr(dfb) if want_in else None, ptr(dW) if want_w else None, ptr(db) if want_w else None, ptr(ws), ws.numel(), 1,
-             ptr(acc) if want_in else None, ptr(x1))
+             ptr(acc) if want_in else None, ptr(x1), None)
         return dfc, dfb, dW, db
     full, ins, wts = mu_bwd(True, True), mu_bwd(True, False), mu_bwd(False, True)
     assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])

@@ -59,9 +59,9 @@ def main():
         try:
             tf = timed(lambda: call("smin_moment_unit_fwd", stream(), ptr(fcm), ptr(fm), ptr(fb), ptr(lay.cells), N, B, L, D, ptr(W), ptr(b), ptr(mu), ptr(x1)), args.iters)
             ti = timed(lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D, ptr(WT),
-                                    ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1)), args.iters)
+                                    ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1), None), args.iters)
             tw = timed(lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D, ptr(WT),
-                                    None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1)), args.iters)
+                                    None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1), None), args.iters)
         finally:
             V.set_gemm_mode("f32")
         if first:

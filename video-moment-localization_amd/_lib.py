@@ -43,10 +43,10 @@ SIGNATURES = {
     "smin_boundary_unit_bwd": [_vp] * 8 + [_i] * 5 + [_vp] * 4 + [_vp] * 6 + [_vp] * 8 + [_vp, _sz],
     "smin_moment_unit_fwd": [_vp] * 5 + [_i] * 4 + [_vp] * 3 + [_vp],
     "smin_pair_product": [_vp] * 3 + [_i] * 3 + [_vp],
-    "smin_moment_unit_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz, _i, _vp, _vp],
+    "smin_moment_unit_bwd": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz, _i, _vp, _vp, _vp],
     "smin_pair_product_bf16": [_vp] * 3 + [_i] * 3 + [_vp],
     "smin_moment_unit_fwd_x1h": [_vp] * 5 + [_i] * 4 + [_vp] * 3 + [_vp],
-    "smin_moment_unit_bwd_x1h": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz, _i, _vp, _vp],
+    "smin_moment_unit_bwd_x1h": [_vp] * 7 + [_i] * 4 + [_vp] * 5 + [_vp, _sz, _i, _vp, _vp, _vp],
     "smin_score_map_fwd": [_vp] * 4 + [_i] * 4 + [_vp] * 7,
     "smin_score_map_bwd": [_vp] * 8 + [_i] * 4 + [_vp] * 3 + [_vp] * 6 + [_vp, _sz],
     "smin_loss_fwd": [_vp] * 14 + [_i] * 2 + [_vp] * 2,

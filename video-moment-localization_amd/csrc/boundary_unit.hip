@@ -35,6 +35,9 @@ void boundary_reduce_bwd_kernel(const float* __restrict__ dfbm, const float* __r
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* arow = Ab + ((size_t)b * L + i) * L;
     float* darow = dAb + ((size_t)b * L + i) * L;
+    // the row's entries outside the cell list are zero: written here (the row belongs to this workgroup), not by a memset launch
+    for (int j = threadIdx.x; j < L; j += 256) darow[j] = 0.f;
+    __syncthreads();
     for (int n = r0 + wave; n < r1; n += 4) {
         const int j = cells[4 * (size_t)n + 2];
         const float a = arow[j];
@@ -341,8 +344,6 @@ extern "C" int smin_boundary_reduce_bwd(void* stream, const float* dfbm, const f
     (void)N;
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
-    hipError_t e = hipMemsetAsync(dAb, 0, sizeof(float) * (size_t)B * L * L, st);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(boundary_reduce_bwd_kernel, dim3(L, B), dim3(256), 0, st, dfbm, Ab, hbar, cells, row_ptr, L, D, dAb, dhbar);
     SMIN_LAUNCH_CHECK();
     return 0;
@@ -406,8 +407,6 @@ extern "C" int smin_boundary_unit_bwd(void* stream, const float* dout, const flo
     SMIN_REQUIRE(off * sizeof(float) <= ws_bytes);
 
     // f_bm = sum_j A hbar :  dA (map term), dhbar
-    hipError_t e = hipMemsetAsync(dAbm, 0, sizeof(float) * (size_t)B * L * L, st);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(boundary_reduce_bwd_kernel, dim3(L, B), dim3(256), 0, st, dout, A, hbar, cells, row_ptr, L, D, dAbm, dhbar);
     SMIN_LAUNCH_CHECK();
     hipLaunchKernelGGL(boundary_self_bwd_rows_kernel, dim3(L, B), dim3(256), sizeof(float) * L, st, dout, dAbm, A, fb, lmask, L, D, scale, draw);

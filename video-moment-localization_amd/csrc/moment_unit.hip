@@ -36,7 +36,8 @@ struct EpSplitStore {               // columns [0, D) -> dX1 (pair-product gradi
 // One 128-thread workgroup per (b, l); gather only -> deterministic.
 __global__ __launch_bounds__(128)
 void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ fb, const int* __restrict__ cells,
-                       const int* __restrict__ row_ptr, const int* __restrict__ cellmap, int B, int L, int D, float* __restrict__ dfb)
+                       const int* __restrict__ row_ptr, const int* __restrict__ cellmap, int B, int L, int D, float* __restrict__ dfb,
+                       const float* __restrict__ dfb_acc)
 {
     // every row of dX1 is read twice, by the workgroup of its start snippet and by that of its end snippet: all workgroups of a
     // sample sit on ONE XCD (ids id and id + 8 share an XCD under round-robin placement: speed only), so that the second read is
@@ -58,6 +59,7 @@ void moment_dfb_kernel(const float* __restrict__ dx1, const float* __restrict__ 
             const int n = cmap[i * L + l];
             if (n >= 0) acc = f4add(acc, f4mul(ldg4(dx1 + (size_t)n * D + d), ldg4(fbb + (size_t)i * D + d)));
         }
+        if (dfb_acc) acc = f4add(acc, ldg4(dfb_acc + ((size_t)b * L + l) * D + d));    // another consumer's gradient of f_b, summed here
         stg4(dfb + ((size_t)b * L + l) * D + d, acc);
     }
 }
@@ -152,7 +154,7 @@ extern "C" int smin_pair_product(void* stream, const float* fb, const int32_t* c
 static int moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                            const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                            float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
-                           const float* dfcmean_acc, const float* x1, const unsigned short* x1h)
+                           const float* dfcmean_acc, const float* x1, const unsigned short* x1h, const float* dfb_acc)
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0 && D <= 2048);
@@ -194,7 +196,7 @@ static int moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, 
         (void)hipMemsetAsync(dbcat, 0, sizeof(float) * (size_t)D, st);
     }
     if (want_in) {
-        hipLaunchKernelGGL(moment_dfb_kernel, dim3(L * 8 * cdiv(B, 8)), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, B, L, D, dfb);
+        hipLaunchKernelGGL(moment_dfb_kernel, dim3(L * 8 * cdiv(B, 8)), dim3(128), 0, st, dx1, fb, cells, row_ptr, cellmap, B, L, D, dfb, dfb_acc);
         SMIN_LAUNCH_CHECK();
     }
     return 0;
@@ -203,16 +205,17 @@ static int moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, 
 extern "C" int smin_moment_unit_bwd(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                                     const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                                     float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
-                                    const float* dfcmean_acc, const float* x1)
+                                    const float* dfcmean_acc, const float* x1, const float* dfb_acc)
 {
-    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, x1, nullptr);
+    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, x1, nullptr,
+                           dfb_acc);
 }
 
 extern "C" int smin_moment_unit_bwd_x1h(void* stream, const float* dmu, const float* fcmean, const float* fb, const int32_t* cells,
                                         const int32_t* row_ptr, const int32_t* cellmap, int N, int B, int L, int D, const float* WcatT,
                                         float* dfcmean, float* dfb, float* dWcat, float* dbcat, void* ws, size_t ws_bytes, int all_valid,
-                                        const float* dfcmean_acc, const uint16_t* x1h)
+                                        const float* dfcmean_acc, const uint16_t* x1h, const float* dfb_acc)
 {
     SMIN_REQUIRE(all_valid && (x1h != nullptr || N == 0));          // the stored product is a plain matrix: mask-driven cell lists only
-    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, nullptr, x1h);
+    return moment_unit_bwd(stream, dmu, fcmean, fb, cells, row_ptr, cellmap, N, B, L, D, WcatT, dfcmean, dfb, dWcat, dbcat, ws, ws_bytes, all_valid, dfcmean_acc, nullptr, x1h, dfb_acc);
 }

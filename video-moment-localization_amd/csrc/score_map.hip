@@ -29,12 +29,14 @@ void score_map_fwd_kernel(const float* __restrict__ fm, const int* __restrict__ 
 
 // one wave per (b, l): the three boundary heads
 __global__ __launch_bounds__(256)
+// (also clears row (b, l) of the dense score map pm [B][L][L]: the cell kernel that follows writes the valid cells only)
 void score_heads_fwd_kernel(const float* __restrict__ fb, int BL, int D, const float* __restrict__ wb, const float* __restrict__ bb,
-                            const float* __restrict__ lmask, float* __restrict__ psea)
+                            const float* __restrict__ lmask, float* __restrict__ psea, float* __restrict__ pm, int L)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= BL) return;
     const int lane = threadIdx.x & 63;
+    for (int j = lane; j < L; j += 64) pm[(size_t)r * L + j] = 0.f;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
     for (int d = lane; d < D; d += 64) {
         const float x = fb[(size_t)r * D + d];
@@ -127,14 +129,12 @@ extern "C" int smin_score_map_fwd(void* stream, const float* fm, const float* fb
 {
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
-    hipError_t e = hipMemsetAsync(pm, 0, sizeof(float) * (size_t)B * L * L, st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(score_heads_fwd_kernel, dim3(cdiv(B * L, 4)), dim3(256), 0, st, fb, B * L, D, wb, bb, lmask, psea, pm, L);
+    SMIN_LAUNCH_CHECK();
     if (N > 0) {
         hipLaunchKernelGGL(score_map_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, fm, cells, N, L, D, wm, bm, pm);
         SMIN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(score_heads_fwd_kernel, dim3(cdiv(B * L, 4)), dim3(256), 0, st, fb, B * L, D, wb, bb, lmask, psea);
-    SMIN_LAUNCH_CHECK();
     return 0;
 }
 

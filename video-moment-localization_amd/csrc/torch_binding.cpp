@@ -634,7 +634,7 @@ struct MomentUnitFn : torch::autograd::Function<MomentUnitFn> {
         Tensor dfcmean = at::empty_like(fcmean), dfb = at::empty_like(fb), dWcat = at::empty_like(Wcat), dbcat = at::empty({D}, fb.options());
         auto ws = scratch(smin_workspace_bytes(N, B, 4, D, 4, 1), fb.device());
         SMIN_CK(smin_moment_unit_bwd(cur(), fp(dmu), fp(fcmean), fp(fb), ip(cells), ip(row_ptr), ip(cellmap), N, B, L, D, fp(WcatT), fpm(dfcmean), fpm(dfb), fpm(dWcat),
-                                     fpm(dbcat), ws.p, ws.n, 1, fp(dacc), fp(x1)));
+                                     fpm(dbcat), ws.p, ws.n, 1, fp(dacc), fp(x1), nullptr));
         return {dfcmean, dmu, dfb, dWcat, dbcat, undef(), undef(), undef()};
     }
 };
@@ -1170,10 +1170,10 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 if (lsk.x1.scalar_type() == at::kBFloat16)
                     SMIN_CK(smin_moment_unit_bwd_x1h(cur(), fp(dfm_in), fp(lsk.cum), fp(lsk.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
-                                                     fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, reinterpret_cast<const uint16_t*>(lsk.x1.const_data_ptr())));
+                                                     fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, reinterpret_cast<const uint16_t*>(lsk.x1.const_data_ptr()), nullptr));
                 else
                     SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm_in), fp(lsk.cum), fp(lsk.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), nullptr, nullptr,
-                                                 fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(lsk.x1)));
+                                                 fpm(dWcat), fpm(dbcat), ws.p, ws.n, 1, nullptr, fp(lsk.x1), nullptr));
                 if (!prep_kernel) {
                     dlp(k, L_FB_W) = dWcat.slice(1, 0, D).contiguous().view_as(lp(k, L_FB_W)); dlp(k, L_FC_W) = dWcat.slice(1, D).contiguous().view_as(lp(k, L_FC_W));
                     dlp(k, L_FB_B) = dbcat; dlp(k, L_FC_B) = dbcat;
@@ -1185,8 +1185,8 @@ struct SminCore : torch::autograd::Function<SminCore> {
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), fpm(dcum), fpm(dfb_mu),
-                                             nullptr, nullptr, ws.p, ws.n, 1, fp(dcum_next), nullptr));          // (the pair product feeds the weight half only)
-            }
+                                             nullptr, nullptr, ws.p, ws.n, 1, fp(dcum_next), nullptr, fp(dfb_next)));   // (the pair product feeds the weight half only)
+            }                                                                      // dfb_mu = this unit's gradient of bu + the later consumer's (dfb_next): dbu
             // boundary unit on the second stream
             // (the boundary unit's gradient of hbar, A[b,i,j] * dbu[b,i,:], is formed by the gate backward itself from A and dbu: no [N][D]
             //  tensor written here and read back there)
@@ -1194,9 +1194,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             wait_stream(side, curs);
             {
                 StreamScope sc(side);
-                const float* two[2] = {fp(dfb_next), fp(dfb_mu)};
-                dbu = at::empty({B, L, D}, opt);
-                SMIN_CK(smin_sum_lists(cur(), two, 2, (size_t)dbu.numel(), fpm(dbu)));
+                dbu = dfb_mu;
                 dfb_k = at::empty({B, L, D}, opt);
                 Tensor dfw = at::empty_like(fw), dfs = at::empty_like(fs);
                 Tensor dWq = at::empty({D, D}, opt), dbq = at::empty({D}, opt), dWk = at::empty({D, D}, opt), dbk = at::empty({D}, opt);

@@ -500,7 +500,7 @@ class MomentUnitFn(Function):
         dWcat, dbcat = torch.empty_like(Wcat), fb.new_empty((D,))
         _, wp, wn = _unit_ws(layout, 4, D, 4, 1, fb.device)
         call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcmean), ptr(fb), ptr(layout.cells), ptr(layout.row_ptr), ptr(layout.cellmap),
-             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid), ptr(dacc), ptr(x1))
+             N, B, L, D, ptr(WcatT), ptr(dfcmean), ptr(dfb), ptr(dWcat), ptr(dbcat), wp, wn, int(layout.all_valid), ptr(dacc), ptr(x1), None)
         return dfcmean, dmu, dfb, dWcat, dbcat, None
 
 
