@@ -306,9 +306,12 @@ int smin_word_prep_bwd(void* stream, const float* const* dwhat, const float* con
 
 /* ---- VideoEncoder (models.py:25-36) fused with the backbone's Hadamard product (models.py:81-83):
  *   fv[b][t][:] = (x[b][t][:] W^T + bias + pe[t][:]) * vmask[b][t]     f[b][t][:] = fv[b][t][:] * fs[b][:]
- * x [B*T][Din], W [D][Din], pe [>=T][D] (rows 0..T-1 are used), vmask [B*T] fp32, fs [B][D]; outputs fv, f [B*T][D]. */
+ * x [B*T][Din], W [D][Din], pe [>=T][D] (rows 0..T-1 are used), vmask [B*T] fp32, fs [B][D]; outputs fv, f [B*T][D].
+ * fs == f == NULL: the projection alone (fv); smin_video_encoder_gate then forms f = fv * fs -- a host can run the projection
+ * beside the query encoder (which produces fs) and pay only the product behind it. */
 int smin_video_encoder_fwd(void* stream, const float* x, const float* W, const float* bias, const float* pe, const float* vmask,
                            const float* fs, int B, int T, int Din, int D, float* fv, float* f);
+int smin_video_encoder_gate(void* stream, const float* fv, const float* fs, int B, int T, int D, float* f);
 size_t smin_video_encoder_bwd_workspace_bytes(int B, int T, int Din, int D);
 /* df [B*T][D] -> dW [D][Din], dbias [D], dpe [T][D], dfs [B][D].  May be issued as two calls on the same ws (e.g. on two streams, the
  * second ordered behind the first): dW == NULL -> inputs half (dfs; the masked gradient stays in ws); df == NULL -> weights half. */

@@ -1025,6 +1025,16 @@ def test_step_helpers_through_the_c_abi(dev):
     df, fv, fs, x = r(B * T, D), r(B * T, D), r(B, D), r(B * T, Din)
     vm = (torch.rand(B * T, generator=g) > 0.2).float().to(dev)
     nbv = lib.smin_video_encoder_bwd_workspace_bytes(B, T, Din, D)
+    # forward: the fused call against projection alone + smin_video_encoder_gate (the step runs the projection beside the query encoder)
+    Wv, bv, pe = r(D, Din), r(D), r(T + 3, D)
+    fv1, f1, fv2, f2 = (torch.full((B * T, D), 7.0, device=dev) for _ in range(4))
+    call("smin_video_encoder_fwd", stream(), ptr(x), ptr(Wv), ptr(bv), ptr(pe), ptr(vm), ptr(fs), B, T, Din, D, ptr(fv1), ptr(f1))
+    call("smin_video_encoder_fwd", stream(), ptr(x), ptr(Wv), ptr(bv), ptr(pe), ptr(vm), None, B, T, Din, D, ptr(fv2), None)
+    call("smin_video_encoder_gate", stream(), ptr(fv2), ptr(fs), B, T, D, ptr(f2))
+    assert torch.equal(fv1, fv2) and torch.equal(f1, f2)
+    ref_fv = ((x.double() @ Wv.double().t() + bv.double()).view(B, T, D) + pe[:T].double()) * vm.view(B, T, 1).double()
+    assert (fv1.view(B, T, D).double() - ref_fv).abs().max().item() < 1e-4
+    assert lib.smin_video_encoder_fwd(stream(), ptr(x), ptr(Wv), ptr(bv), ptr(pe), ptr(vm), ptr(fs), B, T, Din, D, ptr(fv1), None) < 0     # fs without f
 
     def ve_bwd(split):
         ws = torch.zeros(nbv + 64, dtype=torch.uint8, device=dev)

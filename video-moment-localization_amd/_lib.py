@@ -76,6 +76,7 @@ SIGNATURES = {
     "smin_linear_rows_dx_acc": [_vp, _vp, _i, _vp] + [_i] * 3 + [_vp],
     "smin_group_sum": [_vp, _vp, _i, _i, _i, _vp],
     "smin_video_encoder_fwd": [_vp] * 7 + [_i] * 4 + [_vp] * 2,
+    "smin_video_encoder_gate": [_vp] * 3 + [_i] * 3 + [_vp],
     "smin_video_encoder_bwd_workspace_bytes": [_i] * 4,
     "smin_video_encoder_bwd": [_vp] * 6 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
     "smin_bilstm_layer_fwd": [_vp] * 6 + [_i] * 4 + [_vp] * 3,

@@ -876,6 +876,20 @@ struct SminCore : torch::autograd::Function<SminCore> {
         hipEvent_t count_ready = next_event();
         TORCH_CHECK(hipEventRecord(count_ready, curs.stream()) == hipSuccess, "hipEventRecord failed");
 
+        // ---- the video encoder's projection (models.py:25-36) on the second stream, beside the query encoder: only its product with the
+        // sentence feature (models.py:81-83) waits for the LSTM layers (the fused call sat behind them: ~90 us of the step's opening chain)
+        st.vx = cont(video_features);
+        st.fv = at::empty({Bq, T, (int64_t)D}, opt);
+        Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
+        hipEvent_t projection_ready = nullptr;
+        if (prep != curs) {
+            await(prep, count_ready);                                              // (vmaskf)
+            StreamScope sc(prep);
+            SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), nullptr, B, Ti, i32(st.vx.size(2)), D, fpm(st.fv),
+                                           nullptr));
+            projection_ready = mark(prep);
+        }
+
         // ---- backbone (models.py:38-83): BiLSTM x 2, sentence feature, fused video encoder
         Tensor x = cont(query_features);
         for (int layer = 0; layer < 2; ++layer) {
@@ -901,10 +915,12 @@ struct SminCore : torch::autograd::Function<SminCore> {
         fw = fw.contiguous();
         Tensor fs = at::empty({Bq, 2 * H}, opt);                                    // [h_fwd at the last word | h_bwd at the first word]
         SMIN_CK(smin_sentence_feature_fwd(cur(), fp(fw), ip(st.len32), B, i32(fw.size(1)), i32(H), fpm(fs)));
-        st.vx = cont(video_features);
-        st.fv = at::empty({Bq, T, (int64_t)D}, opt);
-        Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
-        SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), fp(fs), B, Ti, i32(st.vx.size(2)), D, fpm(st.fv), fpm(f)));
+        if (projection_ready) {
+            await(curs, projection_ready);
+            SMIN_CK(smin_video_encoder_gate(cur(), fp(st.fv), fp(fs), B, Ti, D, fpm(f)));
+        } else {
+            SMIN_CK(smin_video_encoder_fwd(cur(), fp(st.vx), fp(all[P_VE_W]), fp(all[P_VE_B]), fp(all[P_PE]), fp(st.vmaskf), fp(fs), B, Ti, i32(st.vx.size(2)), D, fpm(st.fv), fpm(f)));
+        }
 
         // ---- layout, part 2
         if (n_known < 0) TORCH_CHECK(hipEventSynchronize(count_ready) == hipSuccess, "hipEventSynchronize failed");

@@ -84,9 +84,49 @@ __global__ void reduce_slabs2_kernel(const float* __restrict__ slabA, float* __r
     if (out2) out2[idx] = v;
 }
 
+// The same sums for MANY slabs of few outputs (P >= 64: the score head's per-chunk partials, 1 575 x 513; a dl x dl weight gradient
+// cut into 768 row splits): a thread per output walked P rows on a handful of workgroups (71 us for 3 MB on the critical path at the
+// start of the backward pass).  Here a workgroup owns 32 outputs and eight threads share each: thread (column, phase) sums rows
+// phase, phase + 8, ... with four sums in flight, the phases meet in LDS in phase order.  Fixed association: reproducible.
+__global__ __launch_bounds__(256)
+void reduce_slabs_wide_kernel(const float* __restrict__ slabA, float* __restrict__ outA, int nA,
+                              const float* __restrict__ slabB, float* __restrict__ outB, int nB, int P, float* __restrict__ outB2)
+{
+    __shared__ float part[8][32];
+    const int col = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    int idx = blockIdx.x * 32 + col;
+    const int blocksA = (nA + 31) / 32;
+    const float* slab = slabA; float* out = outA; int n = nA; float* out2 = nullptr;
+    if ((int)blockIdx.x >= blocksA) { idx = ((int)blockIdx.x - blocksA) * 32 + col; slab = slabB; out = outB; n = nB; out2 = outB2; }
+    const bool ok = idx < n;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        int z = ph;
+        for (; z + 24 < P; z += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += slab[(size_t)(z + 8 * u) * n + idx];
+        }
+        for (; z < P; z += 8) s[0] += slab[(size_t)z * n + idx];
+    }
+    part[ph][col] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (ph == 0 && ok) {
+        float v = part[0][col];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v += part[q][col];
+        out[idx] = v;
+        if (out2) out2[idx] = v;
+    }
+}
+
 int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA, const float* slabB, float* outB, int nB, int P, float* outB2)
 {
     if (nA <= 0 || nB <= 0 || !outB) return launch_reduce_slabs(st, slabA, outA, nA, P);
+    if (P >= 64) {
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3(cdiv(nA, 32) + cdiv(nB, 32)), dim3(256), 0, st, slabA, outA, nA, slabB, outB, nB, P, outB2);
+        SMIN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_slabs2_kernel, dim3(cdiv(nA + nB, 256)), dim3(256), 0, st, slabA, outA, nA, slabB, outB, nB, P, outB2);
     SMIN_LAUNCH_CHECK();
     return 0;
@@ -95,6 +135,11 @@ int launch_reduce_slabs2(hipStream_t st, const float* slabA, float* outA, int nA
 int launch_reduce_slabs(hipStream_t st, const float* slab, float* out, int n, int P)
 {
     if (n <= 0) return 0;
+    if (P >= 64) {
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, slab, out, n, (const float*)nullptr, (float*)nullptr, 0, P, (float*)nullptr);
+        SMIN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, out, n, P);
     SMIN_LAUNCH_CHECK();
     return 0;

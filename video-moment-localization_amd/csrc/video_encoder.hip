@@ -16,7 +16,7 @@ struct EpVideoEnc {                 // row = b*T + t
             const float vm = vmask[row];
             const float4 e = f4scale(f4add(f4add(v, ldg4(bias + col)), ldg4(pe + (size_t)t * N + col)), vm);
             stg4(fv + (size_t)row * N + col, e);
-            stg4(f + (size_t)row * N + col, f4mul(e, ldg4(fs + (size_t)b * N + col)));
+            if (f) stg4(f + (size_t)row * N + col, f4mul(e, ldg4(fs + (size_t)b * N + col)));     // (NULL: smin_video_encoder_gate forms f later)
         });
     }
 };
@@ -68,7 +68,30 @@ extern "C" int smin_video_encoder_fwd(void* stream, const float* x, const float*
                                       const float* fs, int B, int T, int Din, int D, float* fv, float* f)
 {
     SMIN_REQUIRE(Din % 4 == 0 && D % 4 == 0 && B >= 1 && T >= 1);
+    SMIN_REQUIRE((f == nullptr) == (fs == nullptr));
     return launch_gemm_nt((hipStream_t)stream, PlainMat{x, Din}, PlainMat{W, Din}, EpVideoEnc{bias, pe, vmask, fs, fv, f, T}, B * T, D, Din);
+}
+
+// f[b][t][:] = fv[b][t][:] * fs[b][:] -- the Hadamard product alone, for a host that runs the projection (fs == f == NULL above)
+// beside the query encoder, which produces fs
+namespace smin {
+__global__ void video_enc_gate_kernel(const float* __restrict__ fv, const float* __restrict__ fs, int T, int D4, size_t total, float* __restrict__ f)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int d4 = (int)(idx % D4);
+    const size_t b = idx / D4 / T;
+    stg4(f + idx * 4, f4mul(ldg4(fv + idx * 4), ldg4(fs + (b * D4 + d4) * 4)));
+}
+}  // namespace smin
+
+extern "C" int smin_video_encoder_gate(void* stream, const float* fv, const float* fs, int B, int T, int D, float* f)
+{
+    SMIN_REQUIRE(D % 4 == 0 && B >= 1 && T >= 1);
+    const size_t total = (size_t)B * T * (D / 4);
+    hipLaunchKernelGGL(video_enc_gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fv, fs, T, D / 4, total, f);
+    SMIN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t smin_video_encoder_bwd_workspace_bytes(int B, int T, int Din, int D)
