@@ -330,6 +330,10 @@ int smin_sentence_feature_bwd(void* stream, const float* dfs, const int32_t* len
 /* the operand layouts above from nn.LSTM's eight parameter tensors of a layer (w: HOST array of 8 device pointers: weight_ih, weight_hh,
  * bias_ih, bias_hh of the forward direction, then of the reverse direction), one launch; also writes Whh [2][4H][H] for the backward call */
 int smin_lstm_pack(void* stream, const float* const* w, int In, int H, float* Wih, float* bias, float* Whh, float* W4);
+/* every layer of the encoder (nlayers <= 4) in one launch, ahead of the first recurrence: w = HOST array of 8 * nlayers device pointers
+ * (layer by layer, each in smin_lstm_pack's order), In = HOST array of the layers' input widths, outputs = HOST arrays of nlayers pointers */
+int smin_lstm_pack_layers(void* stream, int nlayers, const float* const* w, const int* In, int H, float* const* Wih, float* const* bias,
+                          float* const* Whh, float* const* W4);
 int smin_bilstm_layer_fwd(void* stream, const float* X, const float* Wih_cat, const float* bias_cat, const float* W4,
                           const int32_t* len, int B, int Nq, int In, int H, float* G, float* Hout, float* Cs);
 size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H);

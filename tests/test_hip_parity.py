@@ -1084,6 +1084,20 @@ def test_step_helpers_through_the_c_abi(dev):
         return dX, dWih, dbi, dWhh
     for a, b, c in zip(lstm_bwd(False), lstm_bwd(True), lstm_bwd("pieces")):
         assert torch.equal(a, b) and torch.equal(a, c)
+    # operand layouts: every layer in one launch (smin_lstm_pack_layers) against a launch per layer (smin_lstm_pack)
+    import ctypes
+    ins, raws, one, many = [24, 2 * Hh], [], [], []
+    for In_ in ins:
+        raws.append([r(4 * Hh, In_), r(4 * Hh, Hh), r(4 * Hh), r(4 * Hh), r(4 * Hh, In_), r(4 * Hh, Hh), r(4 * Hh), r(4 * Hh)])
+        one.append([torch.full(sh, 7.0, device=dev) for sh in ((8 * Hh, In_), (8 * Hh,), (2, 4 * Hh, Hh), (2, Hh, Hh, 4))])
+        many.append([torch.full_like(t, 9.0) for t in one[-1]])
+        call("smin_lstm_pack", stream(), (ctypes.c_void_p * 8)(*[t.data_ptr() for t in raws[-1]]), In_, Hh, *[ptr(t) for t in one[-1]])
+    call("smin_lstm_pack_layers", stream(), 2, (ctypes.c_void_p * 16)(*[t.data_ptr() for l in raws for t in l]), (ctypes.c_int * 2)(*ins), Hh,
+         *[(ctypes.c_void_p * 2)(many[0][q].data_ptr(), many[1][q].data_ptr()) for q in range(4)])
+    for l in range(2):
+        for a, b in zip(one[l], many[l]):
+            assert torch.equal(a, b)
+        assert torch.equal(one[l][1], torch.cat([raws[l][2] + raws[l][3], raws[l][6] + raws[l][7]]))
 
 
 @pytest.mark.parametrize("cut", [False, True])

@@ -81,6 +81,7 @@ SIGNATURES = {
     "smin_video_encoder_bwd": [_vp] * 6 + [_i] * 4 + [_vp] * 4 + [_vp, _sz],
     "smin_bilstm_layer_fwd": [_vp] * 6 + [_i] * 4 + [_vp] * 3,
     "smin_lstm_pack": [_vp, _vp, _i, _i] + [_vp] * 4,
+    "smin_lstm_pack_layers": [_vp, _i, _vp, _vp, _i] + [_vp] * 4,
     "smin_lstm_cluster_error": [],
     "smin_sentence_feature_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "smin_sentence_feature_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -239,8 +239,9 @@ __global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int N
 //   Wih [8H][In] = [w_ih; w_ih_reverse],  bias [8H] = [b_ih + b_hh; b_ih_reverse + b_hh_reverse],
 //   Whh [2][4H][H] = {w_hh, w_hh_reverse},  W4 [2][H][H][4] with W4[d][k][u][g] = w_hh_d[g H + u][k]
 struct LstmRaw { const float* w[8]; };              // w_ih, w_hh, b_ih, b_hh, then the same four of the reverse direction
-__global__ void lstm_pack_kernel(LstmRaw R, int In, int H, float* __restrict__ Wih, float* __restrict__ bias, float* __restrict__ Whh,
-                                 float* __restrict__ W4)
+// (pack_layer: one layer's tensors; the kernels below are thin wrappers -- one layer, or every layer of the encoder in one launch)
+__device__ __forceinline__ void pack_layer(const LstmRaw& R, int In, int H, float* __restrict__ Wih, float* __restrict__ bias, float* __restrict__ Whh,
+                                           float* __restrict__ W4)
 {
     const size_t nWih = (size_t)8 * H * In, nB = (size_t)8 * H, nWhh = (size_t)2 * 4 * H * H;
     const size_t tot = nWih + nB + 2 * nWhh;
@@ -264,6 +265,22 @@ __global__ void lstm_pack_kernel(LstmRaw R, int In, int H, float* __restrict__ W
             W4[j] = R.w[d * 4 + 1][((size_t)g * H + u) * H + k];
         }
     }
+}
+__global__ void lstm_pack_kernel(LstmRaw R, int In, int H, float* __restrict__ Wih, float* __restrict__ bias, float* __restrict__ Whh,
+                                 float* __restrict__ W4)
+{
+    pack_layer(R, In, H, Wih, bias, Whh, W4);
+}
+constexpr int LSTM_PACK_MAXL = 4;
+struct LstmPackAll { LstmRaw raw[LSTM_PACK_MAXL]; int In[LSTM_PACK_MAXL]; float* out[LSTM_PACK_MAXL][4]; };
+__global__ void lstm_pack_layers_kernel(LstmPackAll A, int H)
+{
+    const int l = blockIdx.y;                                    // a select chain, not an indexed read of the argument block
+    LstmRaw R = A.raw[0]; int In = A.In[0]; float* o0 = A.out[0][0]; float* o1 = A.out[0][1]; float* o2 = A.out[0][2]; float* o3 = A.out[0][3];
+#pragma unroll
+    for (int k = 1; k < LSTM_PACK_MAXL; ++k)
+        if (l == k) { R = A.raw[k]; In = A.In[k]; o0 = A.out[k][0]; o1 = A.out[k][1]; o2 = A.out[k][2]; o3 = A.out[k][3]; }
+    pack_layer(R, In, H, o0, o1, o2, o3);
 }
 
 
@@ -328,6 +345,25 @@ extern "C" int smin_lstm_pack(void* stream, const float* const* w, int In, int H
     LstmRaw R;
     for (int q = 0; q < 8; ++q) { SMIN_REQUIRE(w[q] != nullptr); R.w[q] = w[q]; }
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, R, In, H, Wih, bias, Whh, W4);
+    SMIN_LAUNCH_CHECK();
+    return 0;
+}
+
+// every layer of the encoder in one launch (w: HOST array of 8 * nlayers device pointers, layer by layer in smin_lstm_pack's order;
+// In: HOST array of the layers' input widths; Wih / bias / Whh / W4: HOST arrays of nlayers device pointers)
+extern "C" int smin_lstm_pack_layers(void* stream, int nlayers, const float* const* w, const int* In, int H, float* const* Wih, float* const* bias,
+                                     float* const* Whh, float* const* W4)
+{
+    SMIN_REQUIRE(nlayers >= 1 && nlayers <= LSTM_PACK_MAXL && H >= 1);
+    LstmPackAll A;
+    for (int l = 0; l < LSTM_PACK_MAXL; ++l) {
+        const int s = l < nlayers ? l : 0;
+        for (int q = 0; q < 8; ++q) { SMIN_REQUIRE(w[8 * s + q] != nullptr); A.raw[l].w[q] = w[8 * s + q]; }
+        SMIN_REQUIRE(In[s] >= 1);
+        A.In[l] = In[s];
+        A.out[l][0] = Wih[s]; A.out[l][1] = bias[s]; A.out[l][2] = Whh[s]; A.out[l][3] = W4[s];
+    }
+    hipLaunchKernelGGL(lstm_pack_layers_kernel, dim3(256, nlayers), dim3(256), 0, (hipStream_t)stream, A, H);
     SMIN_LAUNCH_CHECK();
     return 0;
 }

@@ -892,20 +892,27 @@ struct SminCore : torch::autograd::Function<SminCore> {
 
         // ---- backbone (models.py:38-83): BiLSTM x 2, sentence feature, fused video encoder
         Tensor x = cont(query_features);
+        // both layers' operand layouts in one launch, ahead of the first recurrence (a launch per layer sat between the two)
+        Tensor lstm_bias[2], lstm_W4[2];
+        {
+            const float* raw[16]; int ins[2]; float *wih[2], *bs[2], *whh[2], *w4[2];
+            for (int layer = 0; layer < 2; ++layer) {
+                LstmState& ls = st.lstm[layer];
+                const int64_t In = layer == 0 ? x.size(2) : 2 * H;
+                ls.Wih = at::empty({8 * H, In}, opt);                              // [w_ih; w_ih_reverse]
+                lstm_bias[layer] = at::empty({8 * H}, opt);                        // b_ih + b_hh per direction
+                ls.Whh = at::empty({2, 4 * H, H}, opt);
+                lstm_W4[layer] = at::empty({2, H, H, 4}, opt);                     // [d, k, u, gate]
+                for (int q = 0; q < 8; ++q) raw[8 * layer + q] = fp(all[P_LSTM + 8 * layer + q]);
+                ins[layer] = i32(In); wih[layer] = fpm(ls.Wih); bs[layer] = fpm(lstm_bias[layer]); whh[layer] = fpm(ls.Whh); w4[layer] = fpm(lstm_W4[layer]);
+            }
+            SMIN_CK(smin_lstm_pack_layers(cur(), 2, raw, ins, i32(H), wih, bs, whh, w4));
+        }
         for (int layer = 0; layer < 2; ++layer) {
-            const Tensor* w = &all[P_LSTM + 8 * layer];
             LstmState& ls = st.lstm[layer];
             const int In = i32(x.size(2)), Hh = i32(H);
             ls.x = x;
-            ls.Wih = at::empty({8 * H, (int64_t)In}, opt);                         // [w_ih; w_ih_reverse]
-            Tensor bias = at::empty({8 * H}, opt);                                 // b_ih + b_hh per direction
-            ls.Whh = at::empty({2, 4 * H, H}, opt);
-            Tensor W4 = at::empty({2, H, H, 4}, opt);                              // [d, k, u, gate]
-            {
-                const float* raw[8];
-                for (int q = 0; q < 8; ++q) raw[q] = fp(w[q]);
-                SMIN_CK(smin_lstm_pack(cur(), raw, In, Hh, fpm(ls.Wih), fpm(bias), fpm(ls.Whh), fpm(W4)));
-            }
+            const Tensor &bias = lstm_bias[layer], &W4 = lstm_W4[layer];
             ls.G = at::empty({Bq, Nq_in, 2, 4 * H}, opt); ls.Hout = at::empty({Bq, Nq_in, 2 * H}, opt); ls.Cs = at::empty({Bq, Nq_in, 2, H}, opt);
             SMIN_CK(smin_bilstm_layer_fwd(cur(), fp(x), fp(ls.Wih), fp(bias), fp(W4), ip(st.len32), B, i32(Nq_in), In, Hh, fpm(ls.G), fpm(ls.Hout), fpm(ls.Cs)));
             x = ls.Hout;
