@@ -196,7 +196,8 @@ int smin_moment_unit_bwd_x1h(void* stream, const float* dmu, const float* fcmean
 int smin_score_map_fwd(void* stream, const float* fm, const float* fb, const int32_t* cells, int N, int B, int L, int D,
                        const float* wm, const float* bm, const float* wb, const float* bb, const float* lmask,
                        float* pm, float* psea);
-/* dpm [B][L][L], dpsea [3][B][L] -> dfm [N][D], dfb [B][L][D], dwm [D], dbm [1], dwb [3][D], dbb [3]. */
+/* dpm [B][L][L], dpsea [3][B][L] -> dfm [N][D], dfb [B][L][D], dwm [D], dbm [1], dwb [3][D], dbb [3].  Two independent halves
+ * (map score: dpm -> dfm, dwm, dbm; boundary heads: dpsea -> dfb, dwb, dbb): dpm == NULL or dpsea == NULL skips one (two streams). */
 int smin_score_map_bwd(void* stream, const float* dpm, const float* dpsea, const float* pm, const float* psea,
                        const float* fm, const float* fb, const int32_t* cells, int N, int B, int L, int D,
                        const float* wm, const float* wb, const float* lmask,

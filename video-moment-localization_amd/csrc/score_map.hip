@@ -82,14 +82,16 @@ void score_map_bwd_kernel(const float* __restrict__ dpm, const float* __restrict
     if (threadIdx.x == 0) bpartial[chunk] = bsum;
 }
 
-// chunk of 64 (b,l) rows per workgroup for the three heads
+// chunk of HEAD_ROWS (b,l) rows per workgroup for the three heads (a thread walks its chunk serially, a dependent chain of scalar
+// loads per row: with 64 rows per chunk the 64 workgroups of the ActivityNet shape took 64 us at the opening of the backward pass)
+constexpr int HEAD_ROWS = 8;
 __global__ __launch_bounds__(128)
 void score_heads_bwd_kernel(const float* __restrict__ dpsea, const float* __restrict__ psea, const float* __restrict__ fb,
                             int BL, int D, const float* __restrict__ wb, const float* __restrict__ lmask,
                             float* __restrict__ dfb, float* __restrict__ partial, float* __restrict__ bpartial)
 {
     const int chunk = blockIdx.x;
-    const int r0 = chunk * 64, r1 = min(BL, r0 + 64);
+    const int r0 = chunk * HEAD_ROWS, r1 = min(BL, r0 + HEAD_ROWS);
     float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f;
     for (int d = threadIdx.x * 4; d < D || d == threadIdx.x * 4; d += 512) {
         const bool dok = d < D;
@@ -146,23 +148,32 @@ extern "C" int smin_score_map_bwd(void* stream, const float* dpm, const float* d
     hipStream_t st = (hipStream_t)stream;
     SMIN_REQUIRE(D % 4 == 0);
     const int BL = B * L;
-    const int nch = cdiv(N > 0 ? N : 1, 64), hch = cdiv(BL, 64);
+    const int nch = cdiv(N > 0 ? N : 1, 64), hch = cdiv(BL, HEAD_ROWS);
     float* w = reinterpret_cast<float*>(ws);
     float* part = w;                                   // [nch][D]
     float* bpart = part + (size_t)nch * D;             // [nch]  (padded to 4)
     float* hpart = bpart + ((nch + 3) & ~3);           // [hch][3][D]
     float* hbpart = hpart + (size_t)hch * 3 * D;       // [hch][3]
     SMIN_REQUIRE((size_t)((hbpart + (size_t)hch * 3) - w) * sizeof(float) <= ws_bytes);
-    if (N > 0) {
-        hipLaunchKernelGGL(score_map_bwd_kernel, dim3(nch), dim3(128), 0, st, dpm, pm, fm, cells, N, L, D, wm, dfm, part, bpart);
-        SMIN_LAUNCH_CHECK();
-        int rc = launch_reduce_slabs2(st, part, dwm, D, bpart, dbm, 1, nch); if (rc) return rc;
-    } else {
-        (void)hipMemsetAsync(dwm, 0, sizeof(float) * D, st);
-        (void)hipMemsetAsync(dbm, 0, sizeof(float), st);
+    // two independent halves (the map's score: dpm -> dfm, dwm, dbm; the boundary heads: dpsea -> dfb, dwb, dbb), each with its own part
+    // of ws: dpm == NULL or dpsea == NULL skips a half, so that a host can issue them on two streams
+    SMIN_REQUIRE(dpm != nullptr || dpsea != nullptr);
+    if (dpm) {
+        SMIN_REQUIRE(dwm != nullptr && dbm != nullptr && (dfm != nullptr || N == 0));
+        if (N > 0) {
+            hipLaunchKernelGGL(score_map_bwd_kernel, dim3(nch), dim3(128), 0, st, dpm, pm, fm, cells, N, L, D, wm, dfm, part, bpart);
+            SMIN_LAUNCH_CHECK();
+            int rc = launch_reduce_slabs2(st, part, dwm, D, bpart, dbm, 1, nch); if (rc) return rc;
+        } else {
+            (void)hipMemsetAsync(dwm, 0, sizeof(float) * D, st);
+            (void)hipMemsetAsync(dbm, 0, sizeof(float), st);
+        }
     }
-    hipLaunchKernelGGL(score_heads_bwd_kernel, dim3(hch), dim3(128), 0, st, dpsea, psea, fb, BL, D, wb, lmask, dfb, hpart, hbpart);
-    SMIN_LAUNCH_CHECK();
-    int rc = launch_reduce_slabs2(st, hpart, dwb, 3 * D, hbpart, dbb, 3, hch); if (rc) return rc;
+    if (dpsea) {
+        SMIN_REQUIRE(dfb != nullptr && dwb != nullptr && dbb != nullptr);
+        hipLaunchKernelGGL(score_heads_bwd_kernel, dim3(hch), dim3(128), 0, st, dpsea, psea, fb, BL, D, wb, lmask, dfb, hpart, hbpart);
+        SMIN_LAUNCH_CHECK();
+        int rc = launch_reduce_slabs2(st, hpart, dwb, 3 * D, hbpart, dbb, 3, hch); if (rc) return rc;
+    }
     return 0;
 }

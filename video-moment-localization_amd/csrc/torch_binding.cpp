@@ -877,7 +877,9 @@ struct SminCore : torch::autograd::Function<SminCore> {
         TORCH_CHECK(hipEventRecord(count_ready, curs.stream()) == hipSuccess, "hipEventRecord failed");
 
         // ---- the video encoder's projection (models.py:25-36) on the second stream, beside the query encoder: only its product with the
-        // sentence feature (models.py:81-83) waits for the LSTM layers (the fused call sat behind them: ~90 us of the step's opening chain)
+        // sentence feature (models.py:81-83) waits for the LSTM layers (the fused call sat behind them: ~90 us of the step's opening chain).
+        // Queued behind the parameter products: ahead of them it runs beside the LSTM operand packing and the first recurrence and
+        // stretches both (pack 20 -> 84 us, recurrence 87 -> 130 us: the opening chain 45 us longer, tools/gantt.sh).
         st.vx = cont(video_features);
         st.fv = at::empty({Bq, T, (int64_t)D}, opt);
         Tensor f = at::empty({Bq, T, (int64_t)D}, opt);
@@ -1124,7 +1126,16 @@ struct SminCore : torch::autograd::Function<SminCore> {
         for (int64_t k = 0; k < nl; ++k) for (auto& p : st.layer[k].Pcat) tr_in.push_back(p);
         tr_in.push_back(st.Wch_all);
         tr_in.push_back(st.lstm[0].Wih); tr_in.push_back(st.lstm[1].Wih);
-        std::vector<Tensor> tr = transpose_all(tr_in);
+        // (on the boundary stream, as the boundary heads' backward below: beside the score map's backward on the main stream, which
+        //  otherwise opens the backward pass with four short launches in a row in front of the first contraction)
+        HStream early = (side != curs && (flags & F_OVERLAP_PREP)) ? side : curs;
+        auto mark0 = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
+        wait_stream(early, curs);
+        std::vector<Tensor> tr;
+        {
+            StreamScope sc(early);
+            tr = transpose_all(tr_in);
+        }
         auto trk = [&](int64_t k, int which) -> const Tensor& { return tr[k * TR_PER_LAYER + which]; };
         std::vector<std::vector<Tensor>> PcatT(nl);
         { size_t i = tr_pcat0; for (int64_t k = 0; k < nl; ++k) for (size_t p = 0; p < st.layer[k].Pcat.size(); ++p) PcatT[k].push_back(tr[i++]); }
@@ -1150,9 +1161,24 @@ struct SminCore : torch::autograd::Function<SminCore> {
         std::vector<Tensor> loc_bufs;
         {
             Tensor dwm = at::empty({D}, opt), dbm = at::empty({1}, opt), dwb = at::empty({3, D}, opt), dbb = at::empty({3}, opt);
-            auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
-            SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), fp(dpsea), fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb), fp(lmf),
-                                       fpm(dfm), fpm(dfb_next), fpm(dwm), fpm(dbm), fpm(dwb), fpm(dbb), ws.p, ws.n));
+            if (early != curs) {
+                wait_stream(early, curs);                                          // (behind the allocations above: see "the backward's tail", lesson 2)
+                {
+                    StreamScope sc(early);
+                    auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
+                    SMIN_CK(smin_score_map_bwd(cur(), nullptr, fp(dpsea), fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb),
+                                               fp(lmf), nullptr, fpm(dfb_next), nullptr, nullptr, fpm(dwb), fpm(dbb), ws.p, ws.n));
+                }
+                hipEvent_t early_done = mark0(early);
+                auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
+                SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), nullptr, fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb), fp(lmf),
+                                           fpm(dfm), nullptr, fpm(dwm), fpm(dbm), nullptr, nullptr, ws.p, ws.n));
+                TORCH_CHECK(hipStreamWaitEvent(curs.stream(), early_done, 0) == hipSuccess, "hipStreamWaitEvent failed");    // W^T and dfb_next
+            } else {
+                auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
+                SMIN_CK(smin_score_map_bwd(cur(), fp(dpm), fp(dpsea), fp(st.pm), fp(st.psea), fp(st.fm_out), fp(bu_last), ip(cells), n, B, Li, D, fp(loc[0]), fp(st.wb), fp(lmf),
+                                           fpm(dfm), fpm(dfb_next), fpm(dwm), fpm(dbm), fpm(dwb), fpm(dbb), ws.p, ws.n));
+            }
             Tensor* dloc = &dprm[nl * L_COUNT];
             loc_bufs = {dwm, dbm, dwb, dbb};
             dloc[0] = dwm.view_as(loc[0]); dloc[1] = dbm.view_as(loc[1]);
