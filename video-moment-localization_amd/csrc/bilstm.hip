@@ -368,11 +368,16 @@ extern "C" int smin_lstm_pack_layers(void* stream, int nlayers, const float* con
     return 0;
 }
 
-extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H)
+// floats of the layer backward's workspace up to (not including) the split-K slab of the input-gradient contraction
+static size_t lstm_bwd_ws_floats(int B, int Nq, int In, int H)
 {
     const int R = B * Nq;
     const size_t sp1 = (size_t)tn_splits(R, 8 * H, In), sp2 = (size_t)tn_splits(R, 4 * H, H);
-    return sizeof(float) * ((size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + 2 * sp2 * (size_t)4 * H * H + 256);
+    return (size_t)R * 8 * H + (size_t)2 * R * H + sp1 * ((size_t)8 * H * In + 8 * H) + 2 * sp2 * (size_t)4 * H * H + 256;
+}
+extern "C" size_t smin_bilstm_layer_bwd_workspace_bytes(int B, int Nq, int In, int H)
+{
+    return sizeof(float) * (lstm_bwd_ws_floats(B, Nq, In, H) + (size_t)16 * B * Nq * In);     // + up to 16 partial products of dX
 }
 
 // dHout [B][Nq][2H] -> dX [B*Nq][In] (NULL to skip), dWih_cat [8H][In], dbias_cat [8H], dWhh [2][4H][H].
@@ -404,7 +409,9 @@ extern "C" int smin_bilstm_layer_bwd(void* stream, const float* dHout, const flo
             SMIN_LAUNCH_CHECK();
         }
         if (dX) {
-            rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
+            const int sk = nt_splitk_splits(R, In, H8);
+            if (sk > 1) rc = launch_gemm_nt_splitk(st, dG, H8, Wih_catT, H8, dX, R, In, H8, sk, w + lstm_bwd_ws_floats(B, Nq, In, H));
+            else rc = launch_gemm_nt(st, PlainMat{dG, H8}, PlainMat{Wih_catT, H8}, EpStoreLstm{dX}, R, In, H8);
             if (rc) return rc;
         }
     }

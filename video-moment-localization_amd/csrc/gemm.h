@@ -593,6 +593,46 @@ static inline int launch_gemm_nt(hipStream_t st, const AM& am, const BM_& bm, co
     return 0;
 }
 
+// ------------------------------------------------------------------ NT product of a FEW rows over a LONG contraction, split along K
+// C [M][N] = A [M][K] B[N][K]^T for M of a few tile rows (the LSTM layers' input gradient: 1 280 x 512 x 2 048): the plain engine has
+// 40 tiles for 256 CUs and every workgroup walks all of K alone, a chain of K / 16 load -> barrier -> MFMA steps (110 us on the
+// dependent chain that closes the backward pass).  Here blockIdx.y cuts K into `splits` ranges: 32-row tiles x column tiles x splits
+// workgroups write partial products into slab[split][M][N]; launch_reduce_slabs adds them in split order (fixed: reproducible).
+// Exact-fp32 engine only (the bf16-core modes keep the plain call).
+struct EpSlabStore {
+    float* out;
+    __device__ __forceinline__ void chunk(const float* Ws, int row0, int col0, int ncols, int M, int N, int lane) const {
+        chunk_rows_f4(Ws, row0, col0, ncols, M, N, lane, [&](int row, int col, float4 v) { stg4(out + (size_t)row * N + col, v); });
+    }
+};
+template <int UNUSED>                                          // (a template only for its linkage: the header is included by every source)
+__global__ __launch_bounds__(256, 3)
+void gemm_nt_splitk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ slab, int M, int N, int Ks, int tiles_n)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 20];
+    const int z = blockIdx.y, id = blockIdx.x;
+    gemm_nt_body<true, true>(smem, PlainMat{A + (size_t)z * Ks, lda}, PlainMat{B + (size_t)z * Ks, ldb}, EpSlabStore{slab + (size_t)z * M * N}, M, N, Ks,
+                             (id / tiles_n) * 32, (id % tiles_n) * 128);
+}
+int launch_reduce_slabs(hipStream_t st, const float* slab, float* out, int n, int P);
+// splits for launch_gemm_nt_splitk (1 = use the plain engine): enough workgroups for the chip, at least 16 K-steps per workgroup
+static inline int nt_splitk_splits(int M, int N, int K)
+{
+    const int blocks = cdiv(M, 32) * cdiv(N, 128);
+    if (g_gemm_mode != 0 || blocks * 2 > GEMM_SLOTS || K < 1024) return 1;
+    int s = GEMM_SLOTS * 2 / blocks;
+    while (s > 1 && (K % (16 * s) != 0 || K / s < 256)) --s;
+    return s > 16 ? 16 : s;
+}
+static inline int launch_gemm_nt_splitk(hipStream_t st, const float* A, int lda, const float* B, int ldb, float* out, int M, int N, int K, int splits, float* slab)
+{
+    if (M <= 0 || N <= 0) return 0;
+    const int tiles_n = cdiv(N, 128);
+    hipLaunchKernelGGL(gemm_nt_splitk_kernel<0>, dim3(cdiv(M, 32) * tiles_n, splits), dim3(256), 0, st, A, lda, B, ldb, slab, M, N, K / splits, tiles_n);
+    SMIN_LAUNCH_CHECK();
+    return launch_reduce_slabs(st, slab, out, M * N, splits);
+}
+
 // ------------------------------------------------------------------ TN kernel (weight gradients)
 // slab[z][I][J] = sum over rows m in split z of A[m][i] * B[m][j];  optional bias slab[z][I] = sum_m A[m][i].
 template <class AM, class BM_, bool BIAS>
