@@ -31,8 +31,11 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): smin_build_cells_n; content attention requires dl % 16 == 0; round-2 changes that were not versioned:
- * smin_linear_rows_bwd accepts dW == NULL, smin_video_encoder_bwd / smin_bilstm_layer_bwd may be issued as two halves */
+/* 2 (round 3): smin_build_cells_n, smin_step_prologue, smin_lstm_pack_layers, smin_bilstm_layer_bwd_weights, smin_video_encoder_gate
+ * (smin_video_encoder_fwd with fs == f == NULL), smin_lstm_cluster_error; new trailing arguments of smin_gate_bwd (cells, boundary
+ * A, boundary dout), smin_moment_unit_bwd[_x1h] (dfb_acc) and smin_build_targets; smin_score_map_bwd may be issued as two halves;
+ * content attention requires dl % 16 == 0; round-2 changes that were not versioned: smin_linear_rows_bwd accepts dW == NULL,
+ * smin_video_encoder_bwd / smin_bilstm_layer_bwd may be issued as two halves */
 #define SMIN_HIP_ABI_VERSION 2
 
 int smin_abi_version(void);
