@@ -217,23 +217,6 @@ void bilstm_bwd_kernel(const float* __restrict__ dHout, const float* __restrict_
     }
 }
 
-// Hprev[d][b][p][:] = h of direction d one step before position p: Hout[b][p-1][0:H] (d = 0), Hout[b][p+1][H:2H] (d = 1)
-// (directions d0 .. d0 + nd - 1; Hprev is indexed from direction 0 either way)
-__global__ void bilstm_shift_kernel(const float* __restrict__ Hout, int B, int Nq, int H, float* __restrict__ Hprev, int d0, int nd)
-{
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)nd * B * Nq * H) return;
-    idx += (size_t)d0 * B * Nq * H;
-    const int u = (int)(idx % H);
-    const size_t r = idx / H;
-    const int p = (int)(r % Nq);
-    const size_t bd = r / Nq;
-    const int b = (int)(bd % B), d = (int)(bd / B);
-    const int q = d == 0 ? p - 1 : p + 1;
-    Hprev[idx] = (q >= 0 && q < Nq) ? Hout[((size_t)b * Nq + q) * 2 * H + d * H + u] : 0.f;
-}
-
-
 // The operand layouts of the layer kernels from nn.LSTM's eight parameter tensors of a layer, in one launch (as torch calls: two
 // concatenations, two additions, a stack and a permuted copy per layer, ahead of the first kernel of the step's critical path):
 //   Wih [8H][In] = [w_ih; w_ih_reverse],  bias [8H] = [b_ih + b_hh; b_ih_reverse + b_hh_reverse],
@@ -433,8 +416,7 @@ extern "C" int smin_bilstm_layer_bwd_weights(void* stream, int which, const floa
     const int R = B * Nq, H4 = 4 * H, H8 = 8 * H;
     float* w = reinterpret_cast<float*>(ws);
     float* dG = w;
-    float* Hprev = dG + (size_t)R * H8;
-    float* slab = Hprev + (size_t)2 * R * H;
+    float* slab = dG + (size_t)R * H8 + (size_t)2 * R * H;       // (2 R H floats behind dG: formerly the shifted copy of Hout, unused)
     const int sp1 = tn_splits(R, H8, In), sp2 = tn_splits(R, H4, H);
     float* bslab = slab + (size_t)sp1 * H8 * In;
     float* slab2 = bslab + (size_t)sp1 * H8;
@@ -444,21 +426,12 @@ extern "C" int smin_bilstm_layer_bwd_weights(void* stream, int which, const floa
         rc = launch_gemm_tn(st, PlainMat{dG, H8}, PlainMat{X, In}, slab, bslab, R, H8, In, sp1); if (rc) return rc;
         rc = launch_reduce_slabs2(st, slab, dWih_cat, H8 * In, bslab, dbias_cat, H8, sp1, dbias_cat2); if (rc) return rc;
     }
-    if ((which & 6) == 6) {                                            // both directions on this stream: one shift launch
-        const size_t tot = (size_t)2 * R * H;
-        hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, 0, 2);
-        SMIN_LAUNCH_CHECK();
-    }
     for (int d = 0; d < 2; ++d) {
         if (!(which & (2 << d))) continue;
         SMIN_REQUIRE(dWhh != nullptr);
-        if ((which & 6) != 6) {
-            const size_t tot = (size_t)R * H;
-            hipLaunchKernelGGL(bilstm_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Hout, B, Nq, H, Hprev, d, 1);
-            SMIN_LAUNCH_CHECK();
-        }
+        // h_{t-1} is read straight out of Hout by the operand loader (ShiftRowsMat): no shifted copy, no launch for it
         float* sl = slab2 + (size_t)d * sp2 * H4 * H;
-        rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, PlainMat{Hprev + (size_t)d * R * H, H}, sl, (float*)nullptr, R, H4, H, sp2);
+        rc = launch_gemm_tn(st, PlainMat{dG + (size_t)d * H4, H8}, ShiftRowsMat{Hout, Nq, H, d}, sl, (float*)nullptr, R, H4, H, sp2);
         if (rc) return rc;
         rc = launch_reduce_slabs(st, sl, dWhh + (size_t)d * H4 * H, H4 * H, sp2); if (rc) return rc;
     }

@@ -31,6 +31,23 @@ struct PlainMat {                       // row-major [rows][ld]
     __device__ __forceinline__ float4 at(const Row& r, int c) const { return ldg4(r.p + c); }
 };
 
+// Row (b, pos) of the LSTM output Hout [B][Nq][2H] as the recurrence saw it one step earlier: direction 0 -> columns [0, H) of
+// position pos - 1, direction 1 -> columns [H, 2H) of position pos + 1, zero where that position does not exist (the operand of
+// dW_hh = dG^T h_prev; a kernel of its own wrote this matrix out before)
+struct ShiftRowsMat {
+    const float* p; int Nq, H, d;
+    struct Row { const float* p; float m; };
+    struct Key {};
+    __device__ __forceinline__ Row row(int r) const {
+        const int pos = r % Nq, q = d == 0 ? pos - 1 : pos + 1;
+        const bool ok = q >= 0 && q < Nq;
+        return Row{p + (size_t)(ok ? r + (d == 0 ? -1 : 1) : r) * 2 * H + (size_t)d * H, ok ? 1.f : 0.f};
+    }
+    __device__ __forceinline__ Key key(int) const { return Key{}; }
+    __device__ __forceinline__ Row resolve(const Key&, int r) const { return row(r); }
+    __device__ __forceinline__ float4 at(const Row& r, int c) const { return f4scale(ldg4(r.p + c), r.m); }
+};
+
 struct MaskedRowsMat {                  // row n of [N][ld] scaled by the cell mask m[n]
     const float* p; int ld; const int* cells;
     struct Row { const float* p; float m; };
