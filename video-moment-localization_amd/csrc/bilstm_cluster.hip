@@ -33,6 +33,15 @@ constexpr unsigned CL_SPIN = 1u << 22;
 
 __device__ unsigned int g_lstm_cluster_error;
 
+// -DSMIN_LSTM_STAMPS (tools/lstm_stamps.sh, a diagnostic copy of the library): s_memtime at the phase boundaries of every time step of
+// workgroup 0, [kernel 0 = forward / 1 = backward][step < 64][8 stamps]
+#ifdef SMIN_LSTM_STAMPS
+__device__ unsigned long long g_lstm_stamps[2 * 64 * 8];
+#define LSTM_STAMP(kern, step, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 64) g_lstm_stamps[((kern) * 64 + (step)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSTM_STAMP(kern, step, k) do {} while (0)
+#endif
+
 __device__ __forceinline__ float csigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ void granule_store(unsigned long long* p, float v, unsigned tag) {
@@ -71,6 +80,33 @@ __device__ __forceinline__ void granules_wait(float (&out)[N], const unsigned lo
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = __uint_as_float((unsigned)g[i]);
+}
+
+// 16-byte granules {v0, tag, v1, tag}: two values per L2 transaction.  The backward exchange moves 1 024 values per workgroup and
+// step in each direction and is bound by the number of transactions the L2 retires, not by their bytes (tools/lstm_stamps.sh: with
+// 8-byte granules a step waited 6.9 k cycles for its partial sums, 41 % of the step).  The tag sits in both 8-byte halves, so a
+// reader that sees both tags has both values whether or not the 16-byte store is performed as one piece.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule2_store(unsigned long long* p, float v0, float v1, unsigned tag) {
+    const u32x4 g = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+    // s_nop: gfx9's store-data hazard -- a VMEM store of more than 8 bytes must not be followed at once by an instruction that rewrites
+    // its data registers.  The compiler inserts that wait state for its own stores; it does not look into an asm statement, and the next
+    // granule is built in the same registers (without it: a rare wrong VALUE under a right tag, tools/flaky_probe.py 8 of 239 runs).
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(g) : "memory");
+}
+// seven granules at once (P <= 8: the other workgroups of a cluster): all loads in flight before the first tag is looked at
+__device__ __forceinline__ void granules2_load7(u32x4 (&g)[7], const unsigned long long* const (&p)[7]) {
+    asm volatile("global_load_dwordx4 %0, %7, off sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off sc1\n\t"
+                 "global_load_dwordx4 %3, %10, off sc1\n\t"
+                 "global_load_dwordx4 %4, %11, off sc1\n\t"
+                 "global_load_dwordx4 %5, %12, off sc1\n\t"
+                 "global_load_dwordx4 %6, %13, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6])
+                 : "memory");
 }
 
 // workgroup id -> (cluster, member): the P members of a cluster are ids with the same id % 8, i.e. one XCD under the observed
@@ -116,6 +152,7 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
         float c = 0.f;
         __syncthreads();
         for (int s = 0; s < Nq; ++s) {
+            LSTM_STAMP(0, s, 0);
             const bool act = s < L;
             const int pos = d == 0 ? s : L - 1 - s;
             const size_t row = (size_t)(fin && bme < B ? bme : 0) * Nq + (act ? pos : 0);
@@ -143,7 +180,9 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
             for (int b = 0; b < BS; ++b)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) part[((kq * 4 + q) * BS + b) * U + ul] = a[b][q];
+            LSTM_STAMP(0, s, 1);
             __syncthreads();                                        // partial sums visible; everyone is done reading hs
+            LSTM_STAMP(0, s, 2);
             // the last step's h feeds nothing -- but unless this is the cluster's last pass the exchange still runs: it is what keeps a fast
             // workgroup from overwriting, in its next pass, granules a slow one has not read yet (see the header)
             const bool xchg = P > 1 && (s + 1 < Nq || grp + nclus < ngroups);
@@ -173,6 +212,7 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
                 hs[u * BS + kq] = hn;                               // own units: straight into the local image
                 if (xchg) granule_store(Xs + (size_t)u * BS + kq, hn, tag);
             }
+            LSTM_STAMP(0, s, 3);
             if (xchg) {                                             // gather the other workgroups' units (H * BS <= 1024 granules: four per thread)
                 float v[4];
                 const unsigned long long* ptr[4];
@@ -187,7 +227,9 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (want[i]) hs[tid + 256 * i] = v[i];
             }
+            LSTM_STAMP(0, s, 4);
             __syncthreads();
+            LSTM_STAMP(0, s, 5);
         }
         tagbase += (unsigned)Nq;
     }
@@ -247,6 +289,7 @@ void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __r
         __syncthreads();
         int it = 0;
         for (int s = Nq - 1; s >= 0; --s, ++it) {
+            LSTM_STAMP(1, it, 0);
             const bool act = s < L;
             const GateIn nxt = fetch(s - 1);
             if (fin) {
@@ -274,7 +317,9 @@ void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dgs[(size_t)(q * U + ul) * BS + bq] = dg[q];
             }
+            LSTM_STAMP(1, it, 1);
             __syncthreads();
+            LSTM_STAMP(1, it, 2);
             if (s == 0 && !(P > 1 && grp + nclus < ngroups)) break;   // dh of the step before the first feeds nothing (exchange kept between passes, as in the forward)
             const unsigned gs = tagbase + (unsigned)it, tag = gs + 1u;
             unsigned long long* Xs = X + (size_t)(gs & 1u) * P * P * U * BS;
@@ -291,27 +336,59 @@ void bilstm_cluster_bwd_kernel(const float* __restrict__ dHout, const float* __r
 #pragma unroll
                     for (int b = 0; b < BS; ++b) own[x * BS + b] = a[b];
                 } else {
-                    unsigned long long* o = Xs + (((size_t)dest * P + p) * U + x) * BS;
-#pragma unroll
-                    for (int b = 0; b < BS; ++b) granule_store(o + b, a[b], tag);
+                    unsigned long long* o = Xs + (((size_t)dest * P + p) * U + x) * BS;       // BS = 4 values = two 16-byte granules
+                    granule2_store(o, a[0], a[1], tag);
+                    granule2_store(o + 2, a[2], a[3], tag);
                 }
             }
+            LSTM_STAMP(1, it, 3);
             __syncthreads();                                        // own[] visible; dgs free for the next step
+            LSTM_STAMP(1, it, 4);
             if (fin) {                                              // the owner adds the P partial sums in workgroup order (P <= 8)
-                float v[8];
-                const unsigned long long* ptr[8];
-                bool want[8];
+                // threads of the even samples load the 16-byte granules (their sample and the next one's); the odd samples' threads sit
+                // 32 lanes further in the same wave and take their value from there
+                const bool loader = (bq & 1) == 0;
+                u32x4 g[7];
+                const unsigned long long* ptr[7];
+                int nsrc = 0;
 #pragma unroll
-                for (int src = 0; src < 8; ++src) {
-                    want[src] = src < P && src != p;
-                    ptr[src] = Xs + (((size_t)p * P + (want[src] ? src : 0)) * U + ul) * BS + bq;
+                for (int k = 0; k < 7; ++k) {
+                    const int src = k < p ? k : k + 1;               // the k-th other workgroup
+                    const bool want = src < P;
+                    ptr[k] = Xs + (((size_t)p * P + (want ? src : (p == 0 ? 1 : 0))) * U + ul) * BS + (bq & 2);
+                    nsrc += want ? 1 : 0;
                 }
-                granules_wait<8>(v, ptr, want, tag);
+                if (loader) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        granules2_load7(g, ptr);
+                        bool all = true;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) all = all && (k >= nsrc || (g[k][1] == tag && g[k][3] == tag));
+                        if (all) break;
+                        if (++spins > CL_SPIN) { g_lstm_cluster_error = 1u; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) g[k] = u32x4{0u, 0u, 0u, 0u};
+                }
                 float sum = 0.f;
 #pragma unroll
-                for (int src = 0; src < 8; ++src) if (src < P) sum += src == p ? own[ul * BS + bq] : v[src];
+                for (int src = 0; src < 8; ++src) {
+                    if (src >= P) continue;
+                    float v;
+                    if (src == p) v = own[ul * BS + bq];
+                    else {
+                        const int k = src < p ? src : src - 1;
+                        const float odd = __shfl(__uint_as_float(g[k][2]), (threadIdx.x & 63) ^ 32);     // the loader's second value
+                        v = loader ? __uint_as_float(g[k][0]) : odd;
+                    }
+                    sum += v;
+                }
                 dhn = sum;
             }
+            LSTM_STAMP(1, it, 5);
             cur = nxt;
             // (own[] is rewritten only after the next step's first barrier)
         }
@@ -429,6 +506,14 @@ int launch_bilstm_cluster_bwd(hipStream_t st, const float* dHout, const float* G
 }
 
 }  // namespace smin
+
+#ifdef SMIN_LSTM_STAMPS
+extern "C" int smin_debug_lstm_stamps(unsigned long long* host_out, int n)
+{
+    if (n > 2 * 64 * 8) n = 2 * 64 * 8;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smin::g_lstm_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 // non-zero once a bounded poll of the cluster recurrence has expired (the results of that launch are wrong); clears the word
 extern "C" int smin_lstm_cluster_error(void)
