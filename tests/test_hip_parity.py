@@ -109,6 +109,28 @@ def test_forward_backward_against_golden(dev, name):
     print(name, "worst relative grad error", worst)
 
 
+def test_fused_step_repeats_bit_for_bit(dev):
+    """The one-node step, thirty times on the same weights and batch with the weight stream on and off in turn: every gradient repeats
+    bit for bit.  (What this caught: an asm store of a 16-byte granule without the wait state of the store-data hazard -- a wrong value
+    under a right tag in 3 % of the runs, and only beside the other streams' kernels.)"""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 128, 64, 4, 512, 128, 3, 500, 20, 256, 3
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    b = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=21).items()}
+    ref = None
+    for it in range(30):
+        m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+        m.async_weights = it % 2 == 0
+        out = m(*H.model_inputs(b))
+        loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+        cur = {k: p.grad.clone() for k, p in m.named_parameters()}
+        if ref is None:
+            ref = cur
+        for k in ref:
+            assert torch.equal(ref[k], cur[k]), (it, k)
+
+
 # ---------------------------------------------------------------- full BASELINE shapes vs golden (formula weights)
 @pytest.mark.parametrize("name", ["tacos_yml", "tacos_d500", "charades", "anet_yml", "anet_t256"])
 def test_full_size_against_golden(dev, name):
