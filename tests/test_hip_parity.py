@@ -109,6 +109,29 @@ def test_forward_backward_against_golden(dev, name):
     print(name, "worst relative grad error", worst)
 
 
+def test_float_masks_take_the_torch_prologue(dev):
+    """Masks that are not one byte per element (fp32 0/1 here) leave the one-launch prologue (smin_step_prologue) for torch calls:
+    scores and gradients equal the byte-mask run bit for bit."""
+    from oracle import smin_oracle as O
+    from vml_amd import loss_fn
+    T, L, C, D, dl, layers, Din, Nq, Hh, B = 64, 16, 4, 128, 32, 3, 40, 9, 64, 4
+    sd = O.formula_state_dict(H.smin_shapes(T, L, C, D, dl, layers, Din, Nq, Hh), gain=1.2)
+    b = {k: v.to(dev) for k, v in O.synthetic_batch(B, T, L, Nq, Din, seed=5).items()}
+    res = []
+    for as_float in (False, True):
+        m = build_model(dict(T=T, L=L, C=C, D=D, dl=dl, layers=layers, Din=Din, Nq=Nq, H=Hh), sd, dev)
+        inp = list(H.model_inputs(b))
+        if as_float:
+            inp = [t.float() if i in (1, 3, 4, 5) else t for i, t in enumerate(inp)]          # video / query / length / moment masks
+        out = m(*inp)
+        loss_fn(out[0], b["ym"], b["sm"], b["moment_mask"], out[1], b["ys"], b["ss"], out[2], b["ye"], b["se"], out[3], b["ya"], b["length_mask"]).backward()
+        res.append(([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    for a, c in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, c)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_fused_step_repeats_bit_for_bit(dev):
     """The one-node step, thirty times on the same weights and batch with the weight stream on and off in turn: every gradient repeats
     bit for bit.  (What this caught: an asm store of a 16-byte granule without the wait state of the store-data hazard -- a wrong value
