@@ -1037,6 +1037,28 @@ def test_step_helpers_through_the_c_abi(dev):
     full, ins, wts = mu_bwd(True, True), mu_bwd(True, False), mu_bwd(False, True)
     assert torch.equal(full[0], ins[0]) and torch.equal(full[1], ins[1]) and torch.equal(full[2], wts[2]) and torch.equal(full[3], wts[3])
     assert float(ins[2].min()) == 7.0 and float(wts[0].min()) == 7.0          # the skipped half's outputs are untouched
+    # ... with another consumer's gradient of f_b accumulated into dfb (dfb_acc)
+    dfb_acc = r(B, L, D)
+    dfc2, dfb2 = torch.empty(N, D, device=dev), torch.empty(B, L, D, device=dev)
+    call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D, ptr(WT), ptr(dfc2), ptr(dfb2),
+         None, None, ptr(ws), ws.numel(), 1, ptr(acc), ptr(x1), ptr(dfb_acc))
+    assert torch.equal(dfc2, full[0]) and (dfb2 - (full[1] + dfb_acc)).abs().max().item() <= 1e-6 * max(1.0, float(full[1].abs().max()))
+    # the two halves of the localization backward (map score / boundary heads) against the single call
+    pm, psea, dpm, dpsea = torch.sigmoid(r(B, L, L)), torch.sigmoid(r(3, B, L)), r(B, L, L), r(3, B, L)
+    fm_, wm, wb3, lmk = r(N, D), r(D), r(3, D), (torch.rand(B, L, generator=g) > 0.2).float().to(dev)
+
+    def loc_bwd(map_half, heads_half):
+        dfm_, dfb_, dwm, dbm, dwb, dbb = (torch.full(sh, 7.0, device=dev) for sh in ((N, D), (B, L, D), (D,), (1,), (3, D), (3,)))
+        call("smin_score_map_bwd", stream(), ptr(dpm) if map_half else None, ptr(dpsea) if heads_half else None, ptr(pm), ptr(psea), ptr(fm_), ptr(fb), ptr(lay.cells),
+             N, B, L, D, ptr(wm), ptr(wb3), ptr(lmk), ptr(dfm_) if map_half else None, ptr(dfb_) if heads_half else None, ptr(dwm) if map_half else None,
+             ptr(dbm) if map_half else None, ptr(dwb) if heads_half else None, ptr(dbb) if heads_half else None, ptr(ws), ws.numel())
+        return dfm_, dwm, dbm, dfb_, dwb, dbb
+    both, mp, hd = loc_bwd(True, True), loc_bwd(True, False), loc_bwd(False, True)
+    for q in range(3):
+        assert torch.equal(both[q], mp[q]) and torch.equal(both[3 + q], hd[3 + q])
+        assert float(mp[3 + q].min()) == 7.0 and float(hd[q].min()) == 7.0
+    assert lib.smin_score_map_bwd(stream(), None, None, ptr(pm), ptr(psea), ptr(fm_), ptr(fb), ptr(lay.cells), N, B, L, D, ptr(wm), ptr(wb3), ptr(lmk), None, None, None,
+                                  None, None, None, ptr(ws), ws.numel()) < 0                       # neither half
     R, K, O = 150, 32, 48
     dy, xa, xb = r(R, O), r(R, K), r(R, K)
     WTl = r(2 * K, O)
