@@ -316,8 +316,8 @@ def main():
                                          ptr(WT), ptr(dfc), ptr(dfb), None, None, ptr(ws), ws.numel(), 1, None, ptr(x1), None),
                "moment_dw": lambda: call("smin_moment_unit_bwd", stream(), ptr(dmu), ptr(fcm), ptr(fb_), ptr(lay.cells), ptr(lay.row_ptr), ptr(lay.cellmap), N, B, L, D,
                                          ptr(WT), None, None, ptr(dW), ptr(db), ptr(ws), ws.numel(), 1, None, ptr(x1), None)}
-        for f in fns.values():                                  # warm-up of all three
-            for _ in range(3):
+        for _ in range(12):                                     # warm-up of all three, interleaved: ~35 ms of matrix work (the first
+            for f in fns.values():                              # launches after a pause run ~15 % slow, tools/nt_tail.py)
                 f()
         out = {}
         lib.prof_enable(True)
