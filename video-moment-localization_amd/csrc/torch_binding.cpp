@@ -1199,6 +1199,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
         Tensor dcum_next;                                                          // gradient of cum_k from layer k+1's clip-mean chain
         auto mark_on = [](HStream on) { hipEvent_t e = next_event(); TORCH_CHECK(hipEventRecord(e, on.stream()) == hipSuccess, "hipEventRecord failed"); return e; };
         hipEvent_t attn0_done = nullptr;
+        hipEvent_t boundary_done = nullptr;                                        // the previous iteration's boundary-unit backward (side stream)
         static const bool defer_dw0 = std::getenv("SMIN_DEFER_DW0") && std::atoi(std::getenv("SMIN_DEFER_DW0")) != 0;
         Tensor deferred_dfm;
         std::function<void(const Tensor&)> deferred_weights;
@@ -1231,6 +1232,10 @@ struct SminCore : torch::autograd::Function<SminCore> {
             };
             if (k == 0 && defer_dw0 && wstr != curs) { deferred_dfm = dfm; deferred_weights = moment_weights; }
             else moment_weights(dfm);
+            // the previous layer's boundary-unit backward (second stream) is awaited HERE, where its dfb is first read -- not in front of
+            // that layer's gate backward, which reads nothing of it any more (it forms the unit's dhbar itself): the main stream sat
+            // ~0.6 ms behind the unit's weight contractions at the end of layer 0 (tools/gantt.sh)
+            if (boundary_done) { TORCH_CHECK(hipStreamWaitEvent(curs.stream(), boundary_done, 0) == hipSuccess, "hipStreamWaitEvent failed"); boundary_done = nullptr; }
             {
                 auto ws = scratch(smin_workspace_bytes(n, B, 4, D, 4, 1), dev);
                 SMIN_CK(smin_moment_unit_bwd(cur(), fp(dfm), fp(ls.cum), fp(ls.bu), ip(cells), ip(row_ptr), ip(cellmap), n, B, Li, D, fp(trk(k, TR_CAT)), fpm(dcum), fpm(dfb_mu),
@@ -1257,6 +1262,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 dfs_parts.push_back(dfs); dfw_parts.push_back(dfw);
                 keep.push_back(dfb_next); keep.push_back(dfb_mu); keep.push_back(dbu);
             }
+            if (side != curs) boundary_done = mark_on(side);
             // clip-mean update cum = ccmean Wc^T + b + cumean + hbar: d ccmean, weight gradients; d cumean = d hbar = dcum
             Tensor dccmean = at::empty({N, dl}, opt);
             {
@@ -1339,7 +1345,6 @@ struct SminCore : torch::autograd::Function<SminCore> {
                 }
             }
             // gate: every consumer of hbar_k (clip-mean update, boundary unit, the later layers' running sums) and of f_m (residual; layer 0: the clip-mean chain)
-            wait_stream(curs, side);
             {
                 std::vector<Tensor> later;
                 for (int64_t kk = k + 1; kk < nl; ++kk) later.push_back(dHs[kk]);
@@ -1448,6 +1453,7 @@ struct SminCore : torch::autograd::Function<SminCore> {
             // df = gradient through the proposal map (f_m, f_b) + gradient through the clip-window terms, the second accumulated by its
             // contraction's epilogue
             df = at::empty({B, T, D}, opt);
+            if (boundary_done) { TORCH_CHECK(hipStreamWaitEvent(curs.stream(), boundary_done, 0) == hipSuccess, "hipStreamWaitEvent failed"); boundary_done = nullptr; }   // layer 0's dfb
             auto ws3 = scratch((size_t)4 * B * T * std::max<int64_t>(D, nl * dl), dev);
             SMIN_CK(smin_proposal_map_bwd(cur(), nullptr, fp(dfm), fp(dfb_next), ip(cells), ip(row_ptr), ip(cellmap), n, B, Ti, Li, Ci, D, fpm(df), ws3.p, ws3.n, ip(tab.first),
                                           tab.second.data_ptr()));
