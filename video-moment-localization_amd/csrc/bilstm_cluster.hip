@@ -28,7 +28,6 @@ namespace smin {
 
 constexpr int CL_BS = 4;            // samples per cluster pass
 constexpr int CL_U = 32;            // hidden units per workgroup
-constexpr int CL_KQ = 8;            // forward: contraction split (threads = CL_U * CL_KQ = 256)
 constexpr unsigned CL_SPIN = 1u << 22;
 
 __device__ unsigned int g_lstm_cluster_error;
@@ -120,20 +119,30 @@ __device__ __forceinline__ void cluster_of(int id, int P, int& cluster, int& mem
 // G [B][Nq][2][4H] in: input projections + biases; out: gate activations.  W4 [2][H][H][4] (W4[d][k][u][g] = W_hh_d[gH + u][k]).
 // xch: [nclus][2 parities][H][CL_BS] granules.  grid = nclus_pad * P workgroups of 256 threads; ngroups = ceil(B / CL_BS) * 2 (group, direction) passes
 // are dealt round-robin over the nclus clusters.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256)
 void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ W4, const int* __restrict__ len, int B, int Nq, int H, int P, int nclus,
                                float* __restrict__ Hout, float* __restrict__ Cs, unsigned long long* __restrict__ xch)
 {
+    // The step's contraction z[u][gate][b] = sum_k W[k][u][gate] h[k][b] is 32 units x 4 gates x 4 samples of outputs over K = H: as
+    // v_mfma_f32_4x4x1 -- sixteen independent 4 x 4 outer products per instruction, block = unit, A = the unit's four gate weights of
+    // column k (four consecutive floats of the LDS image), B = h[k] of the four samples -- 2 instructions per k cover the workgroup's
+    // 32 units; the four waves split K and meet in LDS.  (As scalar FMAs the phase was bound by the unpacked fp32 VALU rate: 512 FMAs
+    // per lane and step, 3.6 k of a step's 7.7 k cycles; tools/lstm_stamps.sh.)  Lane (blk, j) of instruction m ends up with the four
+    // gates (registers) of unit 16 m + blk for sample j: the finishing thread of (unit, sample) -- cell state in its registers.
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BS = CL_BS, U = CL_U, KQ = CL_KQ;
-    float4* Wl = reinterpret_cast<float4*>(lds);                   // [H][U] float4 = the four gates of (k, unit)
+    constexpr int BS = CL_BS, U = CL_U;
+    float* Wl = lds;                                               // [H][U][4 gates]
     float* hs = lds + (size_t)H * U * 4;                           // [H][BS]
-    float* part = hs + (size_t)H * BS;                             // [KQ][4 g][BS][U]
+    float* part = hs + (size_t)H * BS;                             // [4 waves][2 instr][4 gates][64 lanes]
     int cluster, p;
     cluster_of(blockIdx.x, P, cluster, p);
     if (cluster >= nclus) return;
-    const int tid = threadIdx.x, ul = tid % U, kq = tid / U;
-    const int u0 = p * U, u = u0 + ul, H4 = 4 * H, kn = H / KQ, k0 = kq * kn;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int u0 = p * U, H4 = 4 * H, kn = H / 4, k0 = wave * kn;
+    // finishing threads: waves 0 and 1 (tid < 128): unit 16 * wave + lane / 4, sample lane % 4
+    const bool fin = tid < 2 * 64;
+    const int ul = 16 * (wave & 1) + (lane >> 2), bq = lane & 3, u = u0 + ul;
     const int ngroups = ((B + BS - 1) / BS) * 2;
     unsigned long long* X = xch + (size_t)cluster * 2 * H * BS;
     unsigned tagbase = 0;                                          // tags grow over the passes of a cluster: no clearing between passes
@@ -143,43 +152,58 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
         __syncthreads();                                           // the previous pass is done with the LDS images
         for (int e = tid; e < H * U; e += 256) {                   // this workgroup's W_hh slice: W4[d][k][u0 .. u0+U)
             const int k = e / U, x = e % U;
-            Wl[e] = *reinterpret_cast<const float4*>(W4 + (((size_t)d * H + k) * H + u0 + x) * 4);
+            *reinterpret_cast<float4*>(Wl + (size_t)e * 4) = *reinterpret_cast<const float4*>(W4 + (((size_t)d * H + k) * H + u0 + x) * 4);
         }
         for (int e = tid; e < H * BS; e += 256) hs[e] = 0.f;
-        const int bme = b0 + kq;                                   // finishing threads: kq < BS -> sample kq of the group
-        const bool fin = kq < BS;
+        const int bme = b0 + bq;                                   // the sample a finishing thread works for
         const int L = (fin && bme < B) ? min(len[bme], Nq) : 0;
         float c = 0.f;
+        // the input projections of step s + 1 are requested while step s contracts (they do not depend on the recurrence): a step that
+        // started with their L2 / HBM round trip spent ~3 k of its 7 k cycles waiting for it, whatever the contraction cost
+        struct Gx { float v[4]; };
+        auto fetch = [&](int s2) {
+            Gx r = {{0.f, 0.f, 0.f, 0.f}};
+            if (s2 < L) {
+                const int pos2 = d == 0 ? s2 : L - 1 - s2;
+                const float* g = G + ((((size_t)bme * Nq + pos2) * 2 + d) * H4) + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r.v[q] = g[q * H];
+            }
+            return r;
+        };
+        Gx gcur = fetch(0);
         __syncthreads();
         for (int s = 0; s < Nq; ++s) {
             LSTM_STAMP(0, s, 0);
             const bool act = s < L;
             const int pos = d == 0 ? s : L - 1 - s;
             const size_t row = (size_t)(fin && bme < B ? bme : 0) * Nq + (act ? pos : 0);
-            float gx[4] = {0.f, 0.f, 0.f, 0.f};
-            if (act) {
-                const float* g = G + (row * 2 + d) * H4 + u;
+            const Gx gnext = fetch(s + 1);
+            float gx[4] = {gcur.v[0], gcur.v[1], gcur.v[2], gcur.v[3]};
+            // four accumulator chains per instruction slot: back-to-back MFMAs into ONE accumulator wait for each other (two chains ran
+            // at the dependent-issue latency: the phase took as long as the scalar version)
+            f32x4m accA[4], accB[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gx[q] = g[q * H];
-            }
-            float a[BS][4];
+            for (int q = 0; q < 4; ++q) { accA[q] = f32x4m{0.f, 0.f, 0.f, 0.f}; accB[q] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+            {
+                const float* wk = Wl + (size_t)k0 * U * 4 + lane;   // units 0..15 of column k: 64 consecutive floats; units 16..31: + 64
+                const float* hk = hs + (size_t)k0 * BS + (lane & 3);
+                for (int kb = 0; kb < kn; kb += 8) {                // kn = H / 4 is a multiple of 8 (H % 32 == 0): eight columns' operands in flight
+                    float a0[8], a1[8], hb[8];
 #pragma unroll
-            for (int b = 0; b < BS; ++b) { a[b][0] = 0.f; a[b][1] = 0.f; a[b][2] = 0.f; a[b][3] = 0.f; }
-#pragma unroll 8
-            for (int k = 0; k < kn; ++k) {
-                const float4 w4 = Wl[(k0 + k) * U + ul];
-                const float4 h4 = *reinterpret_cast<const float4*>(hs + (k0 + k) * BS);
-                const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+                    for (int q = 0; q < 8; ++q) { a0[q] = wk[(size_t)(kb + q) * U * 4]; a1[q] = wk[(size_t)(kb + q) * U * 4 + 64]; hb[q] = hk[(size_t)(kb + q) * BS]; }
 #pragma unroll
-                for (int b = 0; b < BS; ++b) {
-                    a[b][0] = fmaf(hv[b], w4.x, a[b][0]); a[b][1] = fmaf(hv[b], w4.y, a[b][1]);
-                    a[b][2] = fmaf(hv[b], w4.z, a[b][2]); a[b][3] = fmaf(hv[b], w4.w, a[b][3]);
+                    for (int q = 0; q < 8; ++q) {
+                        accA[q & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q], hb[q], accA[q & 3], 0, 0, 0);
+                        accB[q & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q], hb[q], accB[q & 3], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int b = 0; b < BS; ++b)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) part[((kq * 4 + q) * BS + b) * U + ul] = a[b][q];
+            for (int q = 0; q < 4; ++q) {
+                part[((wave * 2 + 0) * 4 + q) * 64 + lane] = (accA[0][q] + accA[1][q]) + (accA[2][q] + accA[3][q]);
+                part[((wave * 2 + 1) * 4 + q) * 64 + lane] = (accB[0][q] + accB[1][q]) + (accB[2][q] + accB[3][q]);
+            }
             LSTM_STAMP(0, s, 1);
             __syncthreads();                                        // partial sums visible; everyone is done reading hs
             LSTM_STAMP(0, s, 2);
@@ -192,11 +216,12 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
                 float hn = 0.f;
                 if (act) {
                     float z[4];
+                    const int m = wave & 1;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float sum = 0.f;
 #pragma unroll
-                        for (int k = 0; k < KQ; ++k) sum += part[((k * 4 + q) * BS + kq) * U + ul];
+                        for (int w = 0; w < 4; ++w) sum += part[((w * 2 + m) * 4 + q) * 64 + lane];
                         z[q] = gx[q] + sum;
                     }
                     const float ig = csigm(z[0]), fg = csigm(z[1]), gg = tanhf(z[2]), og = csigm(z[3]);
@@ -209,8 +234,8 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
                 } else if (bme < B) {
                     Hout[((size_t)bme * Nq + s) * 2 * H + d * H + u] = 0.f;        // padded position s >= len
                 }
-                hs[u * BS + kq] = hn;                               // own units: straight into the local image
-                if (xchg) granule_store(Xs + (size_t)u * BS + kq, hn, tag);
+                hs[u * BS + bq] = hn;                               // own units: straight into the local image
+                if (xchg) granule_store(Xs + (size_t)u * BS + bq, hn, tag);
             }
             LSTM_STAMP(0, s, 3);
             if (xchg) {                                             // gather the other workgroups' units (H * BS <= 1024 granules: four per thread)
@@ -227,6 +252,7 @@ void bilstm_cluster_fwd_kernel(float* __restrict__ G, const float* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (want[i]) hs[tid + 256 * i] = v[i];
             }
+            gcur = gnext;
             LSTM_STAMP(0, s, 4);
             __syncthreads();
             LSTM_STAMP(0, s, 5);
@@ -468,7 +494,7 @@ int launch_bilstm_cluster_fwd(hipStream_t st, float* G, const float* W4, const i
 {
     int P, nclus, grid;
     cl_geometry(B, H, P, nclus, grid);
-    const size_t lds = sizeof(float) * ((size_t)H * CL_U * 4 + (size_t)H * CL_BS + (size_t)CL_KQ * 4 * CL_BS * CL_U);
+    const size_t lds = sizeof(float) * ((size_t)H * CL_U * 4 + (size_t)H * CL_BS + (size_t)4 * 2 * 4 * 64);
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_cluster_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
